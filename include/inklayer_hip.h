@@ -1,0 +1,83 @@
+/*
+ * inklayer_hip.h — C ABI of libinklayer_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the InkLayer detector→segmentor hot path.  The
+ * reference (ooowedyn/InkLayer) is Python on torch.nn modules plus ONE native
+ * op (groundingdino._C.ms_deform_attn_forward).  Every entry point below
+ * replaces one reference call site (cited as file:line under
+ * /root/reference; GD/ = InkLayer/third_party/GroundingDINO/groundingdino/,
+ * SA/ = InkLayer/third_party/segment-anything/segment_anything/).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *     unless a parameter says "host";
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work
+ *     on it (no allocation, no synchronisation: safe under hipGraph capture);
+ *   - return value: 0 = ok, 1 = bad argument (nothing was launched),
+ *     2 = the HIP launch failed;
+ *   - "f16" is IEEE binary16 (_Float16); accumulation is always f32;
+ *   - inputs are borrowed, outputs are caller-allocated.
+ */
+#ifndef INKLAYER_HIP_H
+#define INKLAYER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INK_ABI_VERSION 1
+int ink_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Dense projection:  C[row_map[m], n] = residual[row_map[m], n]
+ *                       + col_scale[n] * act( sum_k A[m,k] * W[n,k] + bias[n] )
+ * W is in nn.Linear layout [N,K] (K contiguous).  MFMA 16x16x32 f16, f32 acc.
+ * Replaces every nn.Linear / 1x1-conv / im2col-conv on the path, e.g.
+ *   SA/modeling/image_encoder.py:231 (qkv), :237 (proj), SA/modeling/common.py:25
+ *   (MLPBlock lin1+GELU+lin2), GD/.../swin_transformer.py:140,170 (qkv/proj),
+ *   GD/.../transformer.py:789-795 (encoder FFN), SA/modeling/mask_decoder.py:53-59
+ *   (ConvTranspose2d k2s2 as a [256 -> 4*64] projection).
+ * Constraints: K % 32 == 0, N % 4 == 0, lda/ldw % 8 == 0, ldc/ldr % 4 == 0,
+ * A/W 16-byte aligned.
+ * --------------------------------------------------------------------- */
+typedef struct InkGemm {
+  const void* A;            /* f16 [M, lda] */
+  const void* W;            /* f16 [N, ldw] */
+  const float* bias;        /* [N] or NULL */
+  const float* col_scale;   /* [N] or NULL */
+  const float* residual;    /* f32 [*, ldr] or NULL; indexed by OUTPUT row */
+  const int32_t* row_map;   /* [M]: output row of input row m, <0 drops the row; NULL = identity */
+  void* C;                  /* f32 or f16 [*, ldc] */
+  int32_t M, N, K;
+  int32_t lda, ldw, ldr, ldc;
+  int32_t act;              /* 0 none, 1 GELU(erf), 2 ReLU */
+  int32_t c_f16;            /* 0: C is f32, 1: C is f16 */
+} InkGemm;
+#define INK_ACT_NONE 0
+#define INK_ACT_GELU 1
+#define INK_ACT_RELU 2
+int ink_gemm_f16(const InkGemm* p, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Row LayerNorm with optional row gather (fuses window-partition / pad /
+ * cyclic shift into the normalisation pass).
+ *   out[r, :] = LN(x[gather[r], :]) * gamma + beta      (gather[r] < 0 -> zeros)
+ * Replaces nn.LayerNorm + window_partition (SA/modeling/image_encoder.py:168-172,
+ * :243-264) and norm1 + pad + roll + window_partition
+ * (GD/.../swin_transformer.py:246-265).  x is f32; out is f16 and/or f32.
+ * C % 4 == 0, C <= 2048.
+ * --------------------------------------------------------------------- */
+int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                       float eps, const int32_t* gather, int32_t rows_out, int32_t C,
+                       void* out_f16, float* out_f32, int64_t ldo, void* stream);
+
+/* f32 -> f16 conversion with optional second addend:  out = f16(a + b)  (b may be NULL).
+ * n % 4 == 0.  Used for "src + pos" operands of GD/.../transformer.py:783. */
+int ink_add_cvt_f16(const float* a, const float* b, void* out_f16, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INKLAYER_HIP_H */

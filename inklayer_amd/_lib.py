@@ -1,0 +1,66 @@
+"""ctypes binding of libinklayer_hip.so (the C ABI declared in include/inklayer_hip.h).
+
+The product path has NO fallback: if the library is missing or fails to load,
+`lib()` raises.  Nothing under oracle/ is ever imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libinklayer_hip.so"
+_lib = None
+
+c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class InkGemm(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("col_scale", c_void_p),
+        ("residual", c_void_p), ("row_map", c_void_p), ("C", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_int), ("ldw", c_int), ("ldr", c_int), ("ldc", c_int),
+        ("act", c_int), ("c_f16", c_int),
+    ]
+
+
+# name -> argtypes; every function returns int (0 ok / 1 bad argument / 2 launch failure)
+SIGNATURES = {
+    "ink_abi_version": [],
+    "ink_gemm_f16": [C.POINTER(InkGemm), c_void_p],
+    "ink_layernorm_rows": [c_void_p, c_i64, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
+                           c_void_p, c_void_p, c_i64, c_void_p],
+    "ink_add_cvt_f16": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
+}
+
+
+class InkLayerHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("INKLAYER_HIP_LIB", _LIB_PATH))
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP library; raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not p.exists():
+            raise InkLayerHipError(
+                f"{p} not found: build it with `python -m inklayer_amd.build` "
+                "(there is no CPU/eager fallback for the InkLayer hot path)")
+        l = C.CDLL(str(p))
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise InkLayerHipError(f"{what} failed: " + {1: "bad argument", 2: "HIP launch error"}.get(rc, str(rc)))

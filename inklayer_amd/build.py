@@ -1,0 +1,66 @@
+"""Build libinklayer_hip.so (gfx950 only) with hipcc.
+
+`python -m inklayer_amd.build` cross-compiles every csrc/*.hip for MI355X and
+links ONE C-ABI shared library in-tree (inklayer_amd/lib/), so it travels to
+the GPU box with the repo snapshot.  No torch headers are involved: the library
+only depends on the HIP runtime.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+CSRC = ROOT / "csrc"
+LIBDIR = ROOT / "lib"
+OBJDIR = LIBDIR / "obj"
+LIB = LIBDIR / "libinklayer_hip.so"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def _newest_header() -> float:
+    hs = list(CSRC.glob("*.h")) + list((ROOT.parent / "include").glob("*.h"))
+    return max(h.stat().st_mtime for h in hs)
+
+
+def _compile(src: Path, force: bool, hdr_time: float) -> Path:
+    obj = OBJDIR / (src.stem + ".o")
+    if (not force and obj.exists() and obj.stat().st_mtime > src.stat().st_mtime
+            and obj.stat().st_mtime > hdr_time):
+        return obj
+    cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    OBJDIR.mkdir(parents=True, exist_ok=True)
+    srcs = sorted(CSRC.glob("*.hip"))
+    if not srcs:
+        raise RuntimeError("no HIP sources found")
+    hdr_time = _newest_header()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, hdr_time), srcs))
+    if (force or not LIB.exists()
+            or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs)):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB),
+               *map(str, objs)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[inklayer_amd.build] {LIB} ({LIB.stat().st_size >> 10} KiB, {len(srcs)} sources)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

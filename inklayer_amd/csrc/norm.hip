@@ -1,0 +1,103 @@
+// Normalisation / conversion kernels (HBM-bound; one wave64 per row, 16-B lanes).
+#include "common.h"
+#include "../../include/inklayer_hip.h"
+
+namespace {
+
+// one wave per output row; row kept in registers (C <= 2048 -> <= 8 float4 per lane)
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, const int32_t* __restrict__ gather, int rows_out,
+    int C, f16* __restrict__ out_h, float* __restrict__ out_f, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows_out) return;
+  const int nv = C >> 2;
+  const int src = gather ? gather[row] : row;
+  if (src < 0) {  // padded token: zeros (the reference pads AFTER the norm)
+    for (int v = lane; v < nv; v += 64) {
+      if (out_h) *(f16x4*)(out_h + row * ldo + v * 4) = (f16x4){0, 0, 0, 0};
+      if (out_f) *(f32x4*)(out_f + row * ldo + v * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
+  const float* xr = x + (int64_t)src * ldx;
+  f32x4 r[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int v = lane + 64 * j;
+    r[j] = v < nv ? *(const f32x4*)(xr + v * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    s += (r[j][0] + r[j][1]) + (r[j][2] + r[j][3]);
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int v = lane + 64 * j;
+    if (v < nv) {
+      const f32x4 d = r[j] - mean;
+      q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int v = lane + 64 * j;
+    if (v < nv) {
+      f32x4 y = (r[j] - mean) * rstd;
+      if (gamma) y *= *(const f32x4*)(gamma + v * 4);
+      if (beta) y += *(const f32x4*)(beta + v * 4);
+      if (out_h) *(f16x4*)(out_h + row * ldo + v * 4) = (f16x4){(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+      if (out_f) *(f32x4*)(out_f + row * ldo + v * 4) = y;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void add_cvt_f16_kernel(const float* __restrict__ a,
+                                                          const float* __restrict__ b,
+                                                          f16* __restrict__ o, int64_t n4) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 v = *(const f32x4*)(a + i * 4);
+    if (b) v += *(const f32x4*)(b + i * 4);
+    *(f16x4*)(o + i * 4) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  }
+}
+
+}  // namespace
+
+extern "C" int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamma,
+                                  const float* beta, float eps, const int32_t* gather,
+                                  int32_t rows_out, int32_t C, void* out_f16, float* out_f32,
+                                  int64_t ldo, void* stream) {
+  INK_CHECK_ARG(x && (out_f16 || out_f32));
+  INK_CHECK_ARG(rows_out > 0 && C > 0 && C % 4 == 0 && C <= 2048);
+  INK_CHECK_ARG(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= C && ldo >= C);
+  const dim3 grid((rows_out + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const int nv = (C / 4 + 63) / 64;
+#define INK_LN(NV)                                                                          \
+  hipLaunchKernelGGL(layernorm_rows_kernel<NV>, grid, block, 0, s, x, ldx, gamma, beta, eps, \
+                     gather, rows_out, C, (f16*)out_f16, out_f32, ldo)
+  switch (nv) {
+    case 1: INK_LN(1); break;
+    case 2: INK_LN(2); break;
+    case 3: INK_LN(3); break;
+    case 4: INK_LN(4); break;
+    case 5: INK_LN(5); break;
+    default: INK_LN(8); break;
+  }
+#undef INK_LN
+  return ink_launch_status();
+}
+
+extern "C" int ink_add_cvt_f16(const float* a, const float* b, void* out_f16, int64_t n,
+                               void* stream) {
+  INK_CHECK_ARG(a && out_f16 && n > 0 && n % 4 == 0);
+  const int64_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(add_cvt_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b,
+                     (f16*)out_f16, n4);
+  return ink_launch_status();
+}
