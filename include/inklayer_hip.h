@@ -77,6 +77,41 @@ int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamma, const fl
  * n % 4 == 0.  Used for "src + pos" operands of GD/.../transformer.py:783. */
 int ink_add_cvt_f16(const float* a, const float* b, void* out_f16, int64_t n, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Fused softmax attention  O = softmax(scale * Q K^T + bias) V   (f16 in/out, f32 math),
+ * never materialising the score matrix.  Rows of batch b start at b*n_q (Q, O) and
+ * b*n_k (K, V); head h occupies columns [h*head_dim, (h+1)*head_dim) of each row, so the
+ * packed qkv projection output is consumed in place (ldq = ldk = ldv = 3*dim).
+ * bias_mode 0: none.
+ * bias_mode 1: SAM global blocks (SA/modeling/image_encoder.py:231-237,325-361) on a 64x64
+ *              token grid: bias[q,k] = scale*(rel_h[q, k/64] + rel_w[q, k%64]); rel_h/rel_w are
+ *              f32 [n_batch*n_heads, n_q, 64] as produced by ink_relpos_bias.
+ * bias_mode 2: SAM 14x14 windows: rel_aug f16 [n_batch*n_heads, n_q, 32] from ink_relpos_bias
+ *              (cols 0..S-1 = rel_h, S..2S-1 = rel_w); grid_w = S.
+ * Supported head_dim: 80 (modes 0,1,2), 32 (mode 0).
+ * --------------------------------------------------------------------- */
+typedef struct InkAttn {
+  const void* Q; const void* K; const void* V;   /* f16 */
+  void* O;                                        /* f16 */
+  int64_t ldq, ldk, ldv, ldo;                     /* row strides in elements */
+  int32_t n_batch, n_heads, n_q, n_k, head_dim;
+  float scale;
+  int32_t bias_mode;
+  int32_t grid_w;
+  const float* rel_h; const float* rel_w;         /* mode 1 */
+  const void* rel_aug;                            /* mode 2 */
+} InkAttn;
+int ink_flash_attn(const InkAttn* p, void* stream);
+
+/* Decomposed relative-position terms of SA/modeling/image_encoder.py:292-361
+ * (get_rel_pos + the two einsums of add_decomposed_rel_pos), divided by `scale`:
+ *   rel_h[bh, q, j] = (Q[b, q, h, :] . rel_pos_h[q_h - j + S - 1, :]) / scale   (same for w).
+ * rel_pos_h / rel_pos_w: f32 [2S-1, head_dim].  S == 64 writes out_h/out_w (f32 [.., 64]);
+ * S <= 16 writes out_aug_f16 ([.., 32], rel_h then rel_w then zeros). */
+int ink_relpos_bias(const void* Q, int64_t ldq, const float* rel_pos_h, const float* rel_pos_w,
+                    int32_t S, int32_t n_batch, int32_t n_heads, int32_t head_dim, float scale,
+                    float* out_h, float* out_w, void* out_aug_f16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,16 @@ class InkGemm(C.Structure):
     ]
 
 
+class InkAttn(C.Structure):
+    _fields_ = [
+        ("Q", c_void_p), ("K", c_void_p), ("V", c_void_p), ("O", c_void_p),
+        ("ldq", c_i64), ("ldk", c_i64), ("ldv", c_i64), ("ldo", c_i64),
+        ("n_batch", c_int), ("n_heads", c_int), ("n_q", c_int), ("n_k", c_int),
+        ("head_dim", c_int), ("scale", c_float), ("bias_mode", c_int), ("grid_w", c_int),
+        ("rel_h", c_void_p), ("rel_w", c_void_p), ("rel_aug", c_void_p),
+    ]
+
+
 # name -> argtypes; every function returns int (0 ok / 1 bad argument / 2 launch failure)
 SIGNATURES = {
     "ink_abi_version": [],
@@ -32,6 +42,9 @@ SIGNATURES = {
     "ink_layernorm_rows": [c_void_p, c_i64, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                            c_void_p, c_void_p, c_i64, c_void_p],
     "ink_add_cvt_f16": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
+    "ink_flash_attn": [C.POINTER(InkAttn), c_void_p],
+    "ink_relpos_bias": [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                        c_void_p, c_void_p, c_void_p, c_void_p],
 }
 
 

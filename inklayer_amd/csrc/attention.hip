@@ -1,0 +1,348 @@
+// Fused (flash-style) attention for gfx950, f16 in / f32 accumulate / f16 out.
+//
+// One wave64 owns 32 query rows; a workgroup of NW waves shares 64-key K/V tiles in LDS.
+//   S^T = K Q^T      mfma_f32_32x32x16_f16(A = K rows, B = Q^T): the lane (q = lane&31) ends up
+//                    with 16 keys of ITS query per 32-key sub-tile -> softmax max/sum are
+//                    in-lane (+ one cross-half shuffle), no LDS round trip.
+//   O^T = V^T P^T    the S^T accumulator is used directly as the B operand (k order permuted
+//                    as cdna_hip_programming.md §3 "accumulator tile as the next MFMA's
+//                    operand"); V^T fragments come from the row-major V tile with
+//                    ds_read_b64_tr_b16 (hardware transpose), so O^T has the query on the
+//                    lane: alpha/l rescaling is lane-local.
+// Bias modes (SAM decomposed relative position, SA/modeling/image_encoder.py:325-361):
+//   1 "row tile"  : global attention on a 64-wide token grid; a 64-key tile is exactly one
+//                   key row, so rel_w[q, kw] sits in 32 registers for the whole kernel and
+//                   rel_h[q, kh] is one scalar per tile; both are folded into the accumulator
+//                   INIT (no per-score VALU work).
+//   2 "augmented" : 14x14 windows; the bias rides in the MFMA: Q' = [q | rel(q,.)/scale],
+//                   K' = [k | onehot(kh), onehot(kw)] (two extra 16-wide k-steps).
+#include "common.h"
+#include "../../include/inklayer_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ f16x4 tr_read(const char* p) {
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+  return __builtin_bit_cast(f16x4, v);
+}
+
+__device__ __forceinline__ f16x8 cvt8(const f32x16& s, int base) {
+  f16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (f16)s[base + j];
+  return r;
+}
+
+template <int HD, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
+  constexpr int NQKB = HD / 16;
+  constexpr int NQK = NQKB + (MODE == 2 ? 2 : 0);
+  constexpr int NB = (HD + 31) / 32;
+  constexpr int DVP = NB * 32;
+  constexpr int CH = HD / 8;                    // 16-B chunks of real data per K/V row
+  constexpr int KROW = ((NQK * 2) | 1) * 16;    // odd chunk count -> conflict-free b128 reads
+  constexpr int VROW = DVP * 2;                 // 64 or 192 B: conflict-free tr_b16 reads
+  constexpr int NT = NW * 64;
+  constexpr int KIT = (64 * CH + NT - 1) / NT;
+  constexpr float NEG = -1e30f;
+  __shared__ __attribute__((aligned(16))) char smem[64 * KROW + 64 * VROW];
+  char* sK = smem;
+  char* sV = smem + 64 * KROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, hh = lane >> 5;
+  const int nqb = (p.n_q + NW * 32 - 1) / (NW * 32);
+  const int bh = blockIdx.x / nqb, qb = blockIdx.x % nqb;
+  const int b = bh / p.n_heads, h = bh % p.n_heads;
+  const int q_idx = qb * NW * 32 + wave * 32 + lq;
+  const bool q_ok = q_idx < p.n_q;
+  const int q_c = q_ok ? q_idx : p.n_q - 1;
+
+  // ---- Q^T fragments (B operand): lane (col = q, half hh) holds Q[q][16 s + 8 hh + j]
+  const f16* Qrow = (const f16*)p.Q + ((int64_t)b * p.n_q + q_c) * p.ldq + h * HD;
+  f16x8 qf[NQK];
+#pragma unroll
+  for (int s = 0; s < NQKB; ++s) qf[s] = *(const f16x8*)(Qrow + 16 * s + 8 * hh);
+  if constexpr (MODE == 2) {
+    const f16* R = (const f16*)p.rel_aug + ((int64_t)bh * p.n_q + q_c) * 32;
+    qf[NQKB] = *(const f16x8*)(R + 8 * hh);
+    qf[NQKB + 1] = *(const f16x8*)(R + 16 + 8 * hh);
+  }
+  float relw[2][16];
+  const float* RH = nullptr;
+  if constexpr (MODE == 1) {
+    const float* RW = p.rel_w + ((int64_t)bh * p.n_q + q_c) * 64;
+    RH = p.rel_h + ((int64_t)bh * p.n_q + q_c) * 64;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *(const f32x4*)(RW + sub * 32 + 8 * g + 4 * hh);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) relw[sub][4 * g + r] = v[r];
+      }
+  }
+
+  // zero the V pad columns once (never overwritten afterwards)
+  if constexpr (DVP > HD) {
+    constexpr int PCH = (DVP - HD) / 8;
+    for (int i = tid; i < 64 * PCH; i += NT) {
+      const int row = i / PCH, cc = CH + i % PCH;
+      *(f16x8*)(sV + row * VROW + cc * 16) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
+  const f16* Kb = (const f16*)p.K + (int64_t)b * p.n_k * p.ldk + h * HD;
+  const f16* Vb = (const f16*)p.V + (int64_t)b * p.n_k * p.ldv + h * HD;
+  f16x8 kreg[KIT], vreg[KIT];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int ci = tid + it * NT;
+      const int row = ci / CH, cc = ci % CH;
+      const int key = t * 64 + row;
+      if (ci < 64 * CH && key < p.n_k) {
+        kreg[it] = *(const f16x8*)(Kb + (int64_t)key * p.ldk + cc * 8);
+        vreg[it] = *(const f16x8*)(Vb + (int64_t)key * p.ldv + cc * 8);
+      } else {
+        kreg[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        vreg[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  };
+  auto store_tile = [&](int t) {
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int ci = tid + it * NT;
+      const int row = ci / CH, cc = ci % CH;
+      if (ci < 64 * CH) {
+        *(f16x8*)(sK + row * KROW + cc * 16) = kreg[it];
+        *(f16x8*)(sV + row * VROW + cc * 16) = vreg[it];
+      }
+    }
+    if constexpr (MODE == 2) {  // one-hot (kh, kw) columns of K'
+      for (int i = tid; i < 256; i += NT) {
+        const int row = i >> 2, c4 = i & 3;
+        const int key = t * 64 + row;
+        const int kh = key / p.grid_w, kw = key - kh * p.grid_w + p.grid_w;
+        f16x8 e;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int col = c4 * 8 + j;
+          e[j] = (key < p.n_k && (col == kh || col == kw)) ? (f16)1 : (f16)0;
+        }
+        *(f16x8*)(sK + row * KROW + (CH + c4) * 16) = e;
+      }
+    }
+  };
+
+  f32x16 o[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = NEG, l_run = 0.f;
+  const float c = p.scale * 1.44269504088896340736f;
+  const int ntiles = (p.n_k + 63) / 64;
+
+  // per-lane LDS read offsets
+  const int koff0 = lq * KROW + hh * 16;
+  const int koff1 = (32 + lq) * KROW + hh * 16;
+  const int voff = (4 * hh + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+  load_tile(0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();  // previous tile fully consumed
+    store_tile(t);
+    __syncthreads();
+    if (t + 1 < ntiles) load_tile(t + 1);  // in flight during the MFMAs below
+
+    f32x16 s0, s1;
+    if constexpr (MODE == 1) {
+      const float rh = RH[t];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = relw[0][r] + rh;
+        s1[r] = relw[1][r] + rh;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < NQK; ++s) {
+      const f16x8 k0 = *(const f16x8*)(sK + koff0 + s * 32);
+      const f16x8 k1 = *(const f16x8*)(sK + koff1 + s * 32);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+    }
+    if ((t + 1) * 64 > p.n_k) {  // ragged last tile: mask keys >= n_k (wave-uniform branch)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 64 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (key >= p.n_k) s0[r] = NEG;
+        if (key + 32 >= p.n_k) s1[r] = NEG;
+      }
+    }
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * c);
+    if (__any(m_new > m_run)) {
+      const float alpha = exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      m_run = m_new;
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = exp2f(fmaf(s0[r], c, -m_run));
+      s1[r] = exp2f(fmaf(s1[r], c, -m_run));
+      ps += s0[r] + s1[r];
+    }
+    l_run += ps;
+    f16x8 pf[4];
+    pf[0] = cvt8(s0, 0);
+    pf[1] = cvt8(s0, 8);
+    pf[2] = cvt8(s1, 0);
+    pf[3] = cvt8(s1, 8);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const char* base = sV + voff + (16 * ks) * VROW + i * 64;
+        const f16x4 a0 = tr_read(base);
+        const f16x4 a1 = tr_read(base + 8 * VROW);
+        const f16x8 vf = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], o[i], 0, 0, 0);
+      }
+    }
+  }
+
+  const float ltot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / ltot;
+  if (q_ok) {
+    f16* Orow = (f16*)p.O + ((int64_t)b * p.n_q + q_idx) * p.ldo + h * HD;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * i + 8 * g + 4 * hh;
+        if (d0 < HD) {
+          const f16x4 v = {(f16)(o[i][4 * g] * inv), (f16)(o[i][4 * g + 1] * inv),
+                           (f16)(o[i][4 * g + 2] * inv), (f16)(o[i][4 * g + 3] * inv)};
+          *(f16x4*)(Orow + d0) = v;
+        }
+      }
+  }
+}
+
+// Decomposed relative-position terms, pre-divided by the softmax scale so that they can sit
+// next to q.k inside the accumulator:  rel_x[q, j] = (q . R_x[q_x - j + S - 1]) / scale.
+// One wave per (batch*head, query); lane = j.   SA/modeling/image_encoder.py:292-361.
+template <int HD>
+__global__ __launch_bounds__(256) void relpos_kernel(const f16* __restrict__ Q, int64_t ldq,
+                                                     const float* __restrict__ Rh,
+                                                     const float* __restrict__ Rw, int S,
+                                                     int n_batch, int n_heads, float inv_scale,
+                                                     float* __restrict__ out_h,
+                                                     float* __restrict__ out_w,
+                                                     f16* __restrict__ out_aug) {
+  const int lane = threadIdx.x & 63;
+  const int n_q = S * S;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= (int64_t)n_batch * n_heads * n_q) return;
+  const int q = (int)(gw % n_q);
+  const int bh = (int)(gw / n_q);
+  const int b = bh / n_heads, h = bh % n_heads;
+  const int qh = q / S, qw = q % S;
+  const f16* qp = Q + ((int64_t)b * n_q + q) * ldq + h * HD;
+  float qv[HD];
+#pragma unroll
+  for (int i = 0; i < HD / 8; ++i) {
+    const f16x8 v = *(const f16x8*)(qp + 8 * i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[8 * i + j] = (float)v[j];
+  }
+  if (out_aug) {  // window form: lanes 0..S-1 -> rel_h, S..2S-1 -> rel_w, rest zero; 32 f16 per query
+    float acc = 0.f;
+    if (lane < 2 * S) {
+      const bool isw = lane >= S;
+      const int j = isw ? lane - S : lane;
+      const float* r = (isw ? Rw + (int64_t)(qw - j + S - 1) * HD : Rh + (int64_t)(qh - j + S - 1) * HD);
+#pragma unroll
+      for (int i = 0; i < HD; ++i) acc = fmaf(qv[i], r[i], acc);
+    }
+    if (lane < 32) out_aug[gw * 32 + lane] = (f16)(acc * inv_scale);
+  } else {  // global form: S == 64, lane = key row / key column
+    const float* rh = Rh + (int64_t)(qh - lane + S - 1) * HD;
+    const float* rw = Rw + (int64_t)(qw - lane + S - 1) * HD;
+    float ah = 0.f, aw = 0.f;
+#pragma unroll
+    for (int i = 0; i < HD; ++i) {
+      ah = fmaf(qv[i], rh[i], ah);
+      aw = fmaf(qv[i], rw[i], aw);
+    }
+    out_h[gw * 64 + lane] = ah * inv_scale;
+    out_w[gw * 64 + lane] = aw * inv_scale;
+  }
+}
+
+}  // namespace
+
+extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
+  INK_CHECK_ARG(pp != nullptr);
+  const InkAttn& p = *pp;
+  INK_CHECK_ARG(p.Q && p.K && p.V && p.O);
+  INK_CHECK_ARG(p.n_batch > 0 && p.n_heads > 0 && p.n_q > 0 && p.n_k > 0);
+  INK_CHECK_ARG(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0);
+  INK_CHECK_ARG((((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) == 0);
+  INK_CHECK_ARG(((uintptr_t)p.O & 7) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int bhn = p.n_batch * p.n_heads;
+#define INK_FA(HD, MODE, NW)                                                              \
+  do {                                                                                    \
+    const int nqb = (p.n_q + NW * 32 - 1) / (NW * 32);                                     \
+    hipLaunchKernelGGL((flash_attn_kernel<HD, MODE, NW>), dim3(bhn * nqb), dim3(NW * 64), 0, s, p); \
+  } while (0)
+  if (p.head_dim == 80 && p.bias_mode == 1) {
+    INK_CHECK_ARG(p.rel_h && p.rel_w && p.grid_w == 64 && p.n_k % 64 == 0);
+    INK_FA(80, 1, 4);
+  } else if (p.head_dim == 80 && p.bias_mode == 2) {
+    INK_CHECK_ARG(p.rel_aug && p.grid_w > 0 && p.grid_w <= 16 && p.n_k <= p.grid_w * p.grid_w);
+    INK_FA(80, 2, 7);
+  } else if (p.head_dim == 80 && p.bias_mode == 0) {
+    INK_FA(80, 0, 4);
+  } else if (p.head_dim == 32 && p.bias_mode == 0) {
+    INK_FA(32, 0, 4);
+  } else {
+    return INK_ERR_ARG;
+  }
+#undef INK_FA
+  return ink_launch_status();
+}
+
+extern "C" int ink_relpos_bias(const void* Q, int64_t ldq, const float* rel_pos_h,
+                               const float* rel_pos_w, int32_t S, int32_t n_batch,
+                               int32_t n_heads, int32_t head_dim, float scale, float* out_h,
+                               float* out_w, void* out_aug_f16, void* stream) {
+  INK_CHECK_ARG(Q && rel_pos_h && rel_pos_w && head_dim == 80 && ldq % 8 == 0);
+  INK_CHECK_ARG(n_batch > 0 && n_heads > 0 && S > 0 && scale > 0.f);
+  if (out_aug_f16) {
+    INK_CHECK_ARG(S <= 16);
+  } else {
+    INK_CHECK_ARG(S == 64 && out_h && out_w);
+  }
+  const int64_t nw = (int64_t)n_batch * n_heads * S * S;
+  hipLaunchKernelGGL(relpos_kernel<80>, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, (const f16*)Q, ldq, rel_pos_h, rel_pos_w, S, n_batch,
+                     n_heads, 1.0f / scale, out_h, out_w, (f16*)out_aug_f16);
+  return ink_launch_status();
+}

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import InkGemm, check
+from ._lib import InkAttn, InkGemm, check
 
 ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2}
 
@@ -97,3 +97,57 @@ def add_cvt_f16(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tens
     check(_lib.lib().ink_add_cvt_f16(a.data_ptr(), _p(b), out.data_ptr(), a.numel(), _stream()),
           "ink_add_cvt_f16")
     return out
+
+
+def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: int, n_heads: int,
+               head_dim: int, scale: float, rel_h: Optional[torch.Tensor] = None,
+               rel_w: Optional[torch.Tensor] = None, rel_aug: Optional[torch.Tensor] = None,
+               grid_w: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(scale*q@k^T + bias)@v for f16 row views q [B*nq, >=H*hd], k/v [B*nk, ...].
+
+    q/k/v may be column slices of one packed qkv buffer (only the row stride matters).
+    """
+    for t in (q, k, v):
+        assert t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1 and t.is_cuda
+    n_q, n_k = q.shape[0] // n_batch, k.shape[0] // n_batch
+    if out is None:
+        out = torch.empty((q.shape[0], n_heads * head_dim), device=q.device, dtype=torch.float16)
+    p = InkAttn()
+    p.Q, p.K, p.V, p.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    p.ldq, p.ldk, p.ldv, p.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    p.n_batch, p.n_heads, p.n_q, p.n_k, p.head_dim = n_batch, n_heads, n_q, n_k, head_dim
+    p.scale = scale
+    p.grid_w = grid_w
+    if rel_aug is not None:
+        assert rel_aug.dtype == torch.float16 and rel_aug.is_contiguous()
+        p.bias_mode, p.rel_aug = 2, rel_aug.data_ptr()
+    elif rel_h is not None:
+        assert rel_h.dtype == torch.float32 and rel_w.dtype == torch.float32
+        assert rel_h.is_contiguous() and rel_w.is_contiguous()
+        p.bias_mode, p.rel_h, p.rel_w = 1, rel_h.data_ptr(), rel_w.data_ptr()
+    else:
+        p.bias_mode = 0
+    check(_lib.lib().ink_flash_attn(C.byref(p), _stream()), "ink_flash_attn")
+    return out
+
+
+def relpos_bias(q: torch.Tensor, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tensor, *, S: int,
+                n_batch: int, n_heads: int, head_dim: int, scale: float):
+    """SAM decomposed rel-pos terms / scale.  S == 64 -> (rel_h, rel_w) f32; S <= 16 -> rel_aug f16."""
+    assert q.dtype == torch.float16 and q.stride(1) == 1
+    assert rel_pos_h.dtype == torch.float32 and rel_pos_h.is_contiguous()
+    assert rel_pos_w.dtype == torch.float32 and rel_pos_w.is_contiguous()
+    assert rel_pos_h.shape == (2 * S - 1, head_dim)
+    n = n_batch * n_heads * S * S
+    fn = _lib.lib().ink_relpos_bias
+    if S == 64:
+        oh = torch.empty((n, 64), device=q.device, dtype=torch.float32)
+        ow = torch.empty((n, 64), device=q.device, dtype=torch.float32)
+        check(fn(q.data_ptr(), q.stride(0), rel_pos_h.data_ptr(), rel_pos_w.data_ptr(), S, n_batch,
+                 n_heads, head_dim, scale, oh.data_ptr(), ow.data_ptr(), None, _stream()),
+              "ink_relpos_bias")
+        return oh, ow
+    aug = torch.empty((n, 32), device=q.device, dtype=torch.float16)
+    check(fn(q.data_ptr(), q.stride(0), rel_pos_h.data_ptr(), rel_pos_w.data_ptr(), S, n_batch,
+             n_heads, head_dim, scale, None, None, aug.data_ptr(), _stream()), "ink_relpos_bias")
+    return aug

@@ -94,3 +94,62 @@ def test_add_cvt(dev):
     b = torch.randn(1000, 256, device=dev)
     assert torch.equal(ops.add_cvt_f16(a, b), (a + b).half())
     assert torch.equal(ops.add_cvt_f16(a), a.half())
+
+
+def _ref_sam_attn(qkv, B, H, hd, S, rph, rpw, scale):
+    """fp64 restatement of SA/modeling/image_encoder.py:224-240 + 325-361 on packed f16 qkv."""
+    N = S * S
+    x = qkv.double().reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)  # 3,B,H,N,hd
+    q, k, v = x[0], x[1], x[2]
+    attn = (q * scale) @ k.transpose(-2, -1)
+    if rph is not None:
+        idx = (torch.arange(S)[:, None] - torch.arange(S)[None, :] + (S - 1)).to(qkv.device)
+        Rh, Rw = rph.double()[idx], rpw.double()[idx]          # S,S,hd
+        rq = q.reshape(B, H, S, S, hd)
+        rel_h = torch.einsum("bnhwc,hkc->bnhwk", rq, Rh)
+        rel_w = torch.einsum("bnhwc,wkc->bnhwk", rq, Rw)
+        attn = (attn.view(B, H, S, S, S, S) + rel_h[..., :, None] + rel_w[..., None, :]).view(B, H, N, N)
+    o = attn.softmax(-1) @ v
+    return o.permute(0, 2, 1, 3).reshape(B * N, H * hd)
+
+
+@pytest.mark.parametrize("S,B,H,relpos", [(14, 5, 2, True), (64, 1, 2, True), (14, 3, 1, False),
+                                          (64, 2, 1, False)])
+def test_flash_attn_sam(dev, S, B, H, relpos):
+    from inklayer_amd import ops
+    hd = 80
+    g = torch.Generator(device="cpu").manual_seed(S + B)
+    qkv = (torch.randn(B * S * S, 3 * H * hd, generator=g) * 1.5).half().to(dev)
+    rph = (torch.randn(2 * S - 1, hd, generator=g) * 0.3).to(dev) if relpos else None
+    rpw = (torch.randn(2 * S - 1, hd, generator=g) * 0.3).to(dev) if relpos else None
+    scale = hd ** -0.5
+    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:2 * H * hd], qkv[:, 2 * H * hd:]
+    kw = {}
+    if relpos:
+        r = ops.relpos_bias(q, rph, rpw, S=S, n_batch=B, n_heads=H, head_dim=hd, scale=scale)
+        if S == 64:
+            kw = dict(rel_h=r[0], rel_w=r[1], grid_w=64)
+        else:
+            kw = dict(rel_aug=r, grid_w=S)
+    out = ops.flash_attn(q, k, v, n_batch=B, n_heads=H, head_dim=hd, scale=scale, **kw)
+    ref = _ref_sam_attn(qkv, B, H, hd, S, rph, rpw, scale)
+    err = (out.double() - ref).abs().max().item()
+    assert torch.isfinite(out).all()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("nq,nk", [(900, 900), (49, 49), (100, 77)])
+def test_flash_attn_hd32(dev, nq, nk):
+    from inklayer_amd import ops
+    B, H, hd = 2, 8, 32
+    g = torch.Generator(device="cpu").manual_seed(nq)
+    q = torch.randn(B * nq, H * hd, generator=g).half().to(dev)
+    k = torch.randn(B * nk, H * hd, generator=g).half().to(dev)
+    v = torch.randn(B * nk, H * hd, generator=g).half().to(dev)
+    out = ops.flash_attn(q, k, v, n_batch=B, n_heads=H, head_dim=hd, scale=hd ** -0.5)
+    qd = q.double().view(B, nq, H, hd).transpose(1, 2)
+    kd = k.double().view(B, nk, H, hd).transpose(1, 2)
+    vd = v.double().view(B, nk, H, hd).transpose(1, 2)
+    ref = ((qd @ kd.transpose(-1, -2)) * hd ** -0.5).softmax(-1) @ vd
+    ref = ref.transpose(1, 2).reshape(B * nq, H * hd)
+    assert (out.double() - ref).abs().max().item() < 3e-3
