@@ -67,15 +67,20 @@ int ink_gemm_f16(const InkGemm* p, void* stream);
  * Replaces nn.LayerNorm + window_partition (SA/modeling/image_encoder.py:168-172,
  * :243-264) and norm1 + pad + roll + window_partition
  * (GD/.../swin_transformer.py:246-265).  x is f32; out is f16 and/or f32.
- * C % 4 == 0, C <= 2048.
+ * C % 4 == 0, C <= 2048.  act: INK_ACT_NONE or INK_ACT_GELU applied after the affine
+ * (LayerNorm2d + GELU of SA/modeling/mask_decoder.py:54-56).
  * --------------------------------------------------------------------- */
 int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamma, const float* beta,
                        float eps, const int32_t* gather, int32_t rows_out, int32_t C,
-                       void* out_f16, float* out_f32, int64_t ldo, void* stream);
+                       void* out_f16, float* out_f32, int64_t ldo, int32_t act, void* stream);
 
-/* f32 -> f16 conversion with optional second addend:  out = f16(a + b)  (b may be NULL).
- * n % 4 == 0.  Used for "src + pos" operands of GD/.../transformer.py:783. */
-int ink_add_cvt_f16(const float* a, const float* b, void* out_f16, int64_t n, void* stream);
+/* f32 -> f16 conversion with optional broadcast addend:  out[i] = f16(a[i] + b[i % n_b])
+ * (b may be NULL).  n % 4 == 0, n_b % 4 == 0, n % n_b == 0.  Used for the "x + pos" operands of
+ * GD/.../transformer.py:783 and SA/modeling/transformer.py:164-165,178-179 (keys + key_pe). */
+int ink_add_cvt_f16(const float* a, const float* b, int64_t n_b, void* out_f16, int64_t n,
+                    void* stream);
+/* Same with an f32 result (src = image_embeddings + dense_prompt, SA/modeling/mask_decoder.py:124-125). */
+int ink_add_f32(const float* a, const float* b, int64_t n_b, float* out, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused softmax attention  O = softmax(scale * Q K^T + bias) V   (f16 in/out, f32 math),
@@ -88,7 +93,10 @@ int ink_add_cvt_f16(const float* a, const float* b, void* out_f16, int64_t n, vo
  *              f32 [n_batch*n_heads, n_q, 64] as produced by ink_relpos_bias.
  * bias_mode 2: SAM 14x14 windows: rel_aug f16 [n_batch*n_heads, n_q, 32] from ink_relpos_bias
  *              (cols 0..S-1 = rel_h, S..2S-1 = rel_w); grid_w = S.
- * Supported head_dim: 80 (modes 0,1,2), 32 (mode 0).
+ * Supported head_dim: 80 (modes 0,1,2), 32 and 16 (mode 0).
+ * q_batch_rows / kv_batch_rows (int32 [n_batch], optional): first row of batch entry b in Q/O and
+ * in K/V; NULL means b*n_q and b*n_k.  Lets many batch entries share one K/V (or Q) block, e.g.
+ * SAM decoder layer 0 where the image keys are identical for all boxes of an image.
  * --------------------------------------------------------------------- */
 typedef struct InkAttn {
   const void* Q; const void* K; const void* V;   /* f16 */
@@ -98,6 +106,8 @@ typedef struct InkAttn {
   float scale;
   int32_t bias_mode;
   int32_t grid_w;
+  const int32_t* q_batch_rows;
+  const int32_t* kv_batch_rows;
   const float* rel_h; const float* rel_w;         /* mode 1 */
   const void* rel_aug;                            /* mode 2 */
 } InkAttn;
@@ -111,6 +121,42 @@ int ink_flash_attn(const InkAttn* p, void* stream);
 int ink_relpos_bias(const void* Q, int64_t ldq, const float* rel_pos_h, const float* rel_pos_w,
                     int32_t S, int32_t n_batch, int32_t n_heads, int32_t head_dim, float scale,
                     float* out_h, float* out_w, void* out_aug_f16, void* stream);
+
+/* Sam.preprocess + PatchEmbed gather (SA/modeling/sam.py:164-174, image_encoder.py:364-395):
+ * image_u8 is the ResizeLongestSide output, HWC uint8 [h, w, 3] (h, w <= L); writes the f16
+ * im2col matrix [ (L/P)^2, 3*P*P ] (column = c*P*P + ky*P + kx, matching proj.weight.view(D,-1)),
+ * with (x - mean[c]) / std[c] applied and the bottom/right padding left at 0.
+ * mean3 / std3 are HOST pointers.  chan_reverse != 0 reads channel 2-c (the BGR/RGB quirk of
+ * InkLayer/segmentor/sam.py:24-26 without an extra host copy). */
+int ink_sam_patchify(const void* image_u8, int32_t h, int32_t w, int32_t L, int32_t P,
+                     const float* mean3, const float* std3, int32_t chan_reverse, void* out_f16,
+                     void* stream);
+
+/* 3x3 / pad-1 im2col of an NHWC f16 map [B,H,W,C] -> [B*H*W, 9*C] with column (ky*3+kx)*C + c
+ * (neck conv SA/modeling/image_encoder.py:96-103; GD input_proj 3x3 s2 uses the strided form). */
+int ink_im2col3x3_f16(const void* in_f16, int32_t B, int32_t H, int32_t W, int32_t C, void* out_f16,
+                      void* stream);
+
+/* PositionEmbeddingRandom._pe_encoding (SA/modeling/prompt_encoder.py:186-193):
+ * out[n] = [sin(2*pi*((2c-1) @ G)), cos(2*pi*((2c-1) @ G))], coords01 f32 [N,2] in [0,1]^2,
+ * G f32 [2,F], out f32 [N,2F]; if `add` (f32 [n_add, 2F]) is given, out[n] += add[n % n_add]
+ * (the learned corner embeddings).  Serves _embed_boxes (:93-100) and get_dense_pe (:62-71). */
+int ink_sam_pe_encode(const float* coords01, const float* gauss, int32_t N, int32_t F,
+                      const float* add, int32_t n_add, float* out, void* stream);
+
+/* masks = hyper_in @ upscaled_embedding for ONE mask token (SA/modeling/mask_decoder.py:139-144),
+ * reading the ConvTranspose output in its un-shuffled GEMM layout
+ * up[((b*g*g + y*g + x)*4 + (dy1*2+dx1))*4 + (dy2*2+dx2), C] and writing the pixel-shuffled
+ * low-res logits out[b, 4y+2dy1+dy2, 4x+2dx1+dx2] (f32 [n, 4g, 4g]).  C in {32, 8}. */
+int ink_sam_mask_logits(const float* up, const float* hyper, int32_t n, int32_t g, int32_t C,
+                        float* out, void* stream);
+
+/* Sam.postprocess_masks + `> mask_threshold` (SA/modeling/sam.py:133-162, SA/predictor.py:238-241)
+ * fused: bilinear S->L (align_corners=False), crop to [in_h,in_w], bilinear to [out_h,out_w],
+ * compare.  out_u8 [n,out_h,out_w] gets 0/1; out_logits (optional, f32) the un-thresholded value. */
+int ink_sam_postprocess(const float* low, int32_t n, int32_t S, int32_t L, int32_t in_h,
+                        int32_t in_w, int32_t out_h, int32_t out_w, float thr, void* out_u8,
+                        float* out_logits, void* stream);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,7 @@ class InkAttn(C.Structure):
         ("ldq", c_i64), ("ldk", c_i64), ("ldv", c_i64), ("ldo", c_i64),
         ("n_batch", c_int), ("n_heads", c_int), ("n_q", c_int), ("n_k", c_int),
         ("head_dim", c_int), ("scale", c_float), ("bias_mode", c_int), ("grid_w", c_int),
+        ("q_batch_rows", c_void_p), ("kv_batch_rows", c_void_p),
         ("rel_h", c_void_p), ("rel_w", c_void_p), ("rel_aug", c_void_p),
     ]
 
@@ -40,9 +41,17 @@ SIGNATURES = {
     "ink_abi_version": [],
     "ink_gemm_f16": [C.POINTER(InkGemm), c_void_p],
     "ink_layernorm_rows": [c_void_p, c_i64, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
-                           c_void_p, c_void_p, c_i64, c_void_p],
-    "ink_add_cvt_f16": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
+                           c_void_p, c_void_p, c_i64, c_int, c_void_p],
+    "ink_add_cvt_f16": [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p],
+    "ink_add_f32": [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p],
     "ink_flash_attn": [C.POINTER(InkAttn), c_void_p],
+    "ink_sam_patchify": [c_void_p, c_int, c_int, c_int, c_int, C.POINTER(c_float), C.POINTER(c_float),
+                         c_int, c_void_p, c_void_p],
+    "ink_im2col3x3_f16": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ink_sam_pe_encode": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
+    "ink_sam_mask_logits": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ink_sam_postprocess": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                            c_void_p, c_void_p, c_void_p],
     "ink_relpos_bias": [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                         c_void_p, c_void_p, c_void_p, c_void_p],
 }

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
   const int q_c = q_ok ? q_idx : p.n_q - 1;
 
   // ---- Q^T fragments (B operand): lane (col = q, half hh) holds Q[q][16 s + 8 hh + j]
-  const f16* Qrow = (const f16*)p.Q + ((int64_t)b * p.n_q + q_c) * p.ldq + h * HD;
+  const int64_t qrow0 = p.q_batch_rows ? (int64_t)p.q_batch_rows[b] : (int64_t)b * p.n_q;
+  const f16* Qrow = (const f16*)p.Q + (qrow0 + q_c) * p.ldq + h * HD;
   f16x8 qf[NQK];
 #pragma unroll
   for (int s = 0; s < NQKB; ++s) qf[s] = *(const f16x8*)(Qrow + 16 * s + 8 * hh);
@@ -94,8 +95,9 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
     }
   }
 
-  const f16* Kb = (const f16*)p.K + (int64_t)b * p.n_k * p.ldk + h * HD;
-  const f16* Vb = (const f16*)p.V + (int64_t)b * p.n_k * p.ldv + h * HD;
+  const int64_t kvb = p.kv_batch_rows ? (int64_t)p.kv_batch_rows[b] : (int64_t)b * p.n_k;
+  const f16* Kb = (const f16*)p.K + kvb * p.ldk + h * HD;
+  const f16* Vb = (const f16*)p.V + kvb * p.ldv + h * HD;
   f16x8 kreg[KIT], vreg[KIT];
   auto load_tile = [&](int t) {
 #pragma unroll
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
   const float ltot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / ltot;
   if (q_ok) {
-    f16* Orow = (f16*)p.O + ((int64_t)b * p.n_q + q_idx) * p.ldo + h * HD;
+    f16* Orow = (f16*)p.O + ((int64_t)b * p.n_q + q_idx) * p.ldo + h * HD;  // O is always dense per batch entry
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -308,10 +310,10 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int bhn = p.n_batch * p.n_heads;
 #define INK_FA(HD, MODE, NW)                                                              \
-  do {                                                                                    \
+  {                                                                                    \
     const int nqb = (p.n_q + NW * 32 - 1) / (NW * 32);                                     \
     hipLaunchKernelGGL((flash_attn_kernel<HD, MODE, NW>), dim3(bhn * nqb), dim3(NW * 64), 0, s, p); \
-  } while (0)
+  }
   if (p.head_dim == 80 && p.bias_mode == 1) {
     INK_CHECK_ARG(p.rel_h && p.rel_w && p.grid_w == 64 && p.n_k % 64 == 0);
     INK_FA(80, 1, 4);
@@ -321,7 +323,9 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
   } else if (p.head_dim == 80 && p.bias_mode == 0) {
     INK_FA(80, 0, 4);
   } else if (p.head_dim == 32 && p.bias_mode == 0) {
-    INK_FA(32, 0, 4);
+    if (p.n_q <= 32) { INK_FA(32, 0, 1) } else { INK_FA(32, 0, 4) }
+  } else if (p.head_dim == 16 && p.bias_mode == 0) {
+    if (p.n_q <= 32) { INK_FA(16, 0, 1) } else { INK_FA(16, 0, 4) }
   } else {
     return INK_ERR_ARG;
   }

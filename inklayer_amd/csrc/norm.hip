@@ -9,7 +9,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, const int32_t* __restrict__ gather, int rows_out,
-    int C, f16* __restrict__ out_h, float* __restrict__ out_f, int64_t ldo) {
+    int C, f16* __restrict__ out_h, float* __restrict__ out_f, int64_t ldo, int act) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows_out) return;
@@ -49,6 +49,10 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
       f32x4 y = (r[j] - mean) * rstd;
       if (gamma) y *= *(const f32x4*)(gamma + v * 4);
       if (beta) y += *(const f32x4*)(beta + v * 4);
+      if (act == INK_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = gelu_erf(y[e]);
+      }
       if (out_h) *(f16x4*)(out_h + row * ldo + v * 4) = (f16x4){(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
       if (out_f) *(f32x4*)(out_f + row * ldo + v * 4) = y;
     }
@@ -57,11 +61,14 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
 
 __global__ __launch_bounds__(256) void add_cvt_f16_kernel(const float* __restrict__ a,
                                                           const float* __restrict__ b,
-                                                          f16* __restrict__ o, int64_t n4) {
+                                                          f16* __restrict__ o,
+                                                          float* __restrict__ of, int64_t n4,
+                                                          int64_t nb4) {
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 v = *(const f32x4*)(a + i * 4);
-    if (b) v += *(const f32x4*)(b + i * 4);
-    *(f16x4*)(o + i * 4) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    if (b) v += *(const f32x4*)(b + (i % nb4) * 4);
+    if (o) *(f16x4*)(o + i * 4) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    if (of) *(f32x4*)(of + i * 4) = v;
   }
 }
 
@@ -70,8 +77,9 @@ __global__ __launch_bounds__(256) void add_cvt_f16_kernel(const float* __restric
 extern "C" int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamma,
                                   const float* beta, float eps, const int32_t* gather,
                                   int32_t rows_out, int32_t C, void* out_f16, float* out_f32,
-                                  int64_t ldo, void* stream) {
+                                  int64_t ldo, int32_t act, void* stream) {
   INK_CHECK_ARG(x && (out_f16 || out_f32));
+  INK_CHECK_ARG(act == INK_ACT_NONE || act == INK_ACT_GELU);
   INK_CHECK_ARG(rows_out > 0 && C > 0 && C % 4 == 0 && C <= 2048);
   INK_CHECK_ARG(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= C && ldo >= C);
   const dim3 grid((rows_out + 3) / 4), block(256);
@@ -79,7 +87,7 @@ extern "C" int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamm
   const int nv = (C / 4 + 63) / 64;
 #define INK_LN(NV)                                                                          \
   hipLaunchKernelGGL(layernorm_rows_kernel<NV>, grid, block, 0, s, x, ldx, gamma, beta, eps, \
-                     gather, rows_out, C, (f16*)out_f16, out_f32, ldo)
+                     gather, rows_out, C, (f16*)out_f16, out_f32, ldo, act)
   switch (nv) {
     case 1: INK_LN(1); break;
     case 2: INK_LN(2); break;
@@ -92,12 +100,24 @@ extern "C" int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamm
   return ink_launch_status();
 }
 
-extern "C" int ink_add_cvt_f16(const float* a, const float* b, void* out_f16, int64_t n,
-                               void* stream) {
+extern "C" int ink_add_cvt_f16(const float* a, const float* b, int64_t n_b, void* out_f16,
+                               int64_t n, void* stream) {
   INK_CHECK_ARG(a && out_f16 && n > 0 && n % 4 == 0);
+  INK_CHECK_ARG(!b || (n_b > 0 && n_b % 4 == 0 && n % n_b == 0));
   const int64_t n4 = n / 4;
   const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(add_cvt_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b,
-                     (f16*)out_f16, n4);
+                     (f16*)out_f16, (float*)nullptr, n4, b ? n_b / 4 : 1);
+  return ink_launch_status();
+}
+
+extern "C" int ink_add_f32(const float* a, const float* b, int64_t n_b, float* out, int64_t n,
+                           void* stream) {
+  INK_CHECK_ARG(a && out && n > 0 && n % 4 == 0);
+  INK_CHECK_ARG(!b || (n_b > 0 && n_b % 4 == 0 && n % n_b == 0));
+  const int64_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(add_cvt_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b,
+                     (f16*)nullptr, out, n4, b ? n_b / 4 : 1);
   return ink_launch_status();
 }

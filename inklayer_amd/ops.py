@@ -1,12 +1,12 @@
 """Thin torch-tensor wrappers over the C ABI (PyTorch = device memory + streams only).
 
-Every function enqueues one hand-written HIP kernel on torch's current stream.
+Every function enqueues hand-written HIP kernels on torch's current stream.
 Tensors must live on the GPU; there is no CPU path.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -14,6 +14,7 @@ from . import _lib
 from ._lib import InkAttn, InkGemm, check
 
 ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2}
+F16, F32 = torch.float16, torch.float32
 
 
 def _stream() -> int:
@@ -30,13 +31,13 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
          act: Optional[str] = None, residual: Optional[torch.Tensor] = None,
          col_scale: Optional[torch.Tensor] = None, row_map: Optional[torch.Tensor] = None,
-         out: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float32,
+         out: Optional[torch.Tensor] = None, out_dtype: torch.dtype = F32,
          out_rows: Optional[int] = None) -> torch.Tensor:
     """out[row_map[m]] = residual[row_map[m]] + col_scale * act(a[m] @ w.T + bias).
 
     a: f16 [M, K] (row stride arbitrary, multiple of 8), w: f16 [N, K].
     """
-    assert a.dtype == torch.float16 and w.dtype == torch.float16
+    assert a.dtype == F16 and w.dtype == F16
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
     M, K = a.shape
     N = w.shape[0]
@@ -50,79 +51,116 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     p.bias, p.col_scale = _p(bias), _p(col_scale)
     p.residual, p.row_map = _p(residual), _p(row_map)
     if bias is not None:
-        assert bias.dtype == torch.float32 and bias.numel() == N
+        assert bias.dtype == F32 and bias.numel() == N
     if col_scale is not None:
-        assert col_scale.dtype == torch.float32 and col_scale.numel() == N
+        assert col_scale.dtype == F32 and col_scale.numel() == N
     if residual is not None:
-        assert residual.dtype == torch.float32 and residual.stride(1) == 1 and residual.shape[1] == N
+        assert residual.dtype == F32 and residual.stride(1) == 1 and residual.shape[1] == N
         p.ldr = residual.stride(0)
     if row_map is not None:
         assert row_map.dtype == torch.int32 and row_map.numel() == M
     p.M, p.N, p.K = M, N, K
     p.lda, p.ldw, p.ldc = a.stride(0), w.stride(0), out.stride(0)
     p.act = ACT[act]
-    p.c_f16 = 1 if out.dtype == torch.float16 else 0
-    assert out.dtype in (torch.float16, torch.float32)
+    p.c_f16 = 1 if out.dtype == F16 else 0
+    assert out.dtype in (F16, F32)
     check(_lib.lib().ink_gemm_f16(C.byref(p), _stream()), "ink_gemm_f16")
     return out
 
 
 def layernorm_rows(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor],
                    eps: float, *, gather: Optional[torch.Tensor] = None,
-                   out_dtype: torch.dtype = torch.float16,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """LayerNorm over the last dim of f32 x [R, C]; optional row gather (-1 -> zero row)."""
-    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+                   out_dtype: torch.dtype = F16, out: Optional[torch.Tensor] = None,
+                   out2: Optional[torch.Tensor] = None, act: Optional[str] = None) -> torch.Tensor:
+    """LayerNorm over the last dim of f32 x [R, C]; optional row gather (-1 -> zero row).
+    `out2` (the other of f16/f32, same shape/stride) receives a second copy in the same pass."""
+    assert x.dtype == F32 and x.dim() == 2 and x.stride(1) == 1
     Cdim = x.shape[1]
     rows = gather.numel() if gather is not None else x.shape[0]
     if out is None:
         out = torch.empty((rows, Cdim), device=x.device, dtype=out_dtype)
     assert out.shape == (rows, Cdim) and out.stride(1) == 1
-    oh = out.data_ptr() if out.dtype == torch.float16 else None
-    of = out.data_ptr() if out.dtype == torch.float32 else None
+    oh = out.data_ptr() if out.dtype == F16 else None
+    of = out.data_ptr() if out.dtype == F32 else None
+    if out2 is not None:
+        assert out2.shape == out.shape and out2.stride(0) == out.stride(0) and out2.dtype != out.dtype
+        if out2.dtype == F16:
+            oh = out2.data_ptr()
+        else:
+            of = out2.data_ptr()
     if gather is not None:
         assert gather.dtype == torch.int32
     check(_lib.lib().ink_layernorm_rows(x.data_ptr(), x.stride(0), _p(gamma), _p(beta), eps,
-                                        _p(gather), rows, Cdim, oh, of, out.stride(0), _stream()),
-          "ink_layernorm_rows")
+                                        _p(gather), rows, Cdim, oh, of, out.stride(0), ACT[act],
+                                        _stream()), "ink_layernorm_rows")
     return out
 
 
-def add_cvt_f16(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """f16(a + b) for contiguous f32 tensors."""
-    assert a.dtype == torch.float32 and a.is_contiguous()
+def add_cvt_f16(a: torch.Tensor, b: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f16(a + b) for contiguous f32 tensors; b may be a (leading-dim) broadcast of a."""
+    assert a.dtype == F32 and a.is_contiguous()
+    nb = 0
     if b is not None:
-        assert b.dtype == torch.float32 and b.is_contiguous() and b.shape == a.shape
-    out = torch.empty(a.shape, device=a.device, dtype=torch.float16)
-    check(_lib.lib().ink_add_cvt_f16(a.data_ptr(), _p(b), out.data_ptr(), a.numel(), _stream()),
+        assert b.dtype == F32 and b.is_contiguous() and a.numel() % b.numel() == 0
+        nb = b.numel()
+    if out is None:
+        out = torch.empty(a.shape, device=a.device, dtype=F16)
+    assert out.dtype == F16 and out.is_contiguous() and out.numel() == a.numel()
+    check(_lib.lib().ink_add_cvt_f16(a.data_ptr(), _p(b), nb, out.data_ptr(), a.numel(), _stream()),
           "ink_add_cvt_f16")
     return out
 
 
+def add_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a + b (f32), b broadcast along the leading dims of a (periodic in flat index)."""
+    assert a.dtype == F32 and b.dtype == F32 and a.is_contiguous() and b.is_contiguous()
+    assert a.numel() % b.numel() == 0
+    if out is None:
+        out = torch.empty(a.shape, device=a.device, dtype=F32)
+    assert out.is_contiguous() and out.numel() == a.numel()
+    check(_lib.lib().ink_add_f32(a.data_ptr(), b.data_ptr(), b.numel(), out.data_ptr(), a.numel(),
+                                 _stream()), "ink_add_f32")
+    return out
+
+
 def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: int, n_heads: int,
-               head_dim: int, scale: float, rel_h: Optional[torch.Tensor] = None,
-               rel_w: Optional[torch.Tensor] = None, rel_aug: Optional[torch.Tensor] = None,
-               grid_w: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """softmax(scale*q@k^T + bias)@v for f16 row views q [B*nq, >=H*hd], k/v [B*nk, ...].
+               head_dim: int, scale: float, n_q: Optional[int] = None, n_k: Optional[int] = None,
+               rel_h: Optional[torch.Tensor] = None, rel_w: Optional[torch.Tensor] = None,
+               rel_aug: Optional[torch.Tensor] = None, grid_w: int = 0,
+               q_batch_rows: Optional[torch.Tensor] = None,
+               kv_batch_rows: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(scale*q@k^T + bias)@v for f16 row views q [.., >=H*hd], k/v [.., >=H*hd].
 
     q/k/v may be column slices of one packed qkv buffer (only the row stride matters).
+    Batch entry b uses rows q_batch_rows[b] + [0, n_q) of q and kv_batch_rows[b] + [0, n_k) of
+    k/v (defaults b*n_q, b*n_k); the output is dense [n_batch*n_q, H*hd].
     """
     for t in (q, k, v):
-        assert t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1 and t.is_cuda
-    n_q, n_k = q.shape[0] // n_batch, k.shape[0] // n_batch
+        assert t.dtype == F16 and t.dim() == 2 and t.stride(1) == 1 and t.is_cuda
+    if n_q is None:
+        n_q = q.shape[0] // n_batch
+    if n_k is None:
+        n_k = k.shape[0] // n_batch
     if out is None:
-        out = torch.empty((q.shape[0], n_heads * head_dim), device=q.device, dtype=torch.float16)
+        out = torch.empty((n_batch * n_q, n_heads * head_dim), device=q.device, dtype=F16)
+    assert out.dtype == F16 and out.shape[0] == n_batch * n_q and out.stride(1) == 1
     p = InkAttn()
     p.Q, p.K, p.V, p.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
     p.ldq, p.ldk, p.ldv, p.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     p.n_batch, p.n_heads, p.n_q, p.n_k, p.head_dim = n_batch, n_heads, n_q, n_k, head_dim
     p.scale = scale
     p.grid_w = grid_w
+    for name, t in (("q_batch_rows", q_batch_rows), ("kv_batch_rows", kv_batch_rows)):
+        if t is not None:
+            assert t.dtype == torch.int32 and t.numel() == n_batch and t.is_cuda
+            setattr(p, name, t.data_ptr())
     if rel_aug is not None:
-        assert rel_aug.dtype == torch.float16 and rel_aug.is_contiguous()
+        assert rel_aug.dtype == F16 and rel_aug.is_contiguous()
         p.bias_mode, p.rel_aug = 2, rel_aug.data_ptr()
     elif rel_h is not None:
-        assert rel_h.dtype == torch.float32 and rel_w.dtype == torch.float32
+        assert rel_h.dtype == F32 and rel_w.dtype == F32
         assert rel_h.is_contiguous() and rel_w.is_contiguous()
         p.bias_mode, p.rel_h, p.rel_w = 1, rel_h.data_ptr(), rel_w.data_ptr()
     else:
@@ -132,22 +170,90 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: in
 
 
 def relpos_bias(q: torch.Tensor, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tensor, *, S: int,
-                n_batch: int, n_heads: int, head_dim: int, scale: float):
+                n_batch: int, n_heads: int, head_dim: int, scale: float, out=None):
     """SAM decomposed rel-pos terms / scale.  S == 64 -> (rel_h, rel_w) f32; S <= 16 -> rel_aug f16."""
-    assert q.dtype == torch.float16 and q.stride(1) == 1
-    assert rel_pos_h.dtype == torch.float32 and rel_pos_h.is_contiguous()
-    assert rel_pos_w.dtype == torch.float32 and rel_pos_w.is_contiguous()
+    assert q.dtype == F16 and q.stride(1) == 1
+    assert rel_pos_h.dtype == F32 and rel_pos_h.is_contiguous()
+    assert rel_pos_w.dtype == F32 and rel_pos_w.is_contiguous()
     assert rel_pos_h.shape == (2 * S - 1, head_dim)
     n = n_batch * n_heads * S * S
     fn = _lib.lib().ink_relpos_bias
     if S == 64:
-        oh = torch.empty((n, 64), device=q.device, dtype=torch.float32)
-        ow = torch.empty((n, 64), device=q.device, dtype=torch.float32)
+        oh, ow = out if out is not None else (torch.empty((n, 64), device=q.device, dtype=F32),
+                                              torch.empty((n, 64), device=q.device, dtype=F32))
+        assert oh.numel() >= n * 64 and ow.numel() >= n * 64
         check(fn(q.data_ptr(), q.stride(0), rel_pos_h.data_ptr(), rel_pos_w.data_ptr(), S, n_batch,
                  n_heads, head_dim, scale, oh.data_ptr(), ow.data_ptr(), None, _stream()),
               "ink_relpos_bias")
         return oh, ow
-    aug = torch.empty((n, 32), device=q.device, dtype=torch.float16)
+    aug = out if out is not None else torch.empty((n, 32), device=q.device, dtype=F16)
+    assert aug.numel() >= n * 32
     check(fn(q.data_ptr(), q.stride(0), rel_pos_h.data_ptr(), rel_pos_w.data_ptr(), S, n_batch,
              n_heads, head_dim, scale, None, None, aug.data_ptr(), _stream()), "ink_relpos_bias")
     return aug
+
+
+def sam_patchify(image_u8: torch.Tensor, L: int, P: int, mean: Sequence[float],
+                 std: Sequence[float], chan_reverse: bool, out: torch.Tensor) -> torch.Tensor:
+    """uint8 HWC (h,w <= L) -> normalised, zero-padded f16 im2col [ (L/P)^2, 3*P*P ]."""
+    assert image_u8.dtype == torch.uint8 and image_u8.is_cuda and image_u8.is_contiguous()
+    h, w, c = image_u8.shape
+    assert c == 3 and out.dtype == F16 and out.is_contiguous()
+    assert out.numel() == (L // P) ** 2 * 3 * P * P
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    check(_lib.lib().ink_sam_patchify(image_u8.data_ptr(), h, w, L, P, m, s, int(chan_reverse),
+                                      out.data_ptr(), _stream()), "ink_sam_patchify")
+    return out
+
+
+def im2col3x3(x: torch.Tensor, B: int, H: int, W: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f16 NHWC [B*H*W, C] -> [B*H*W, 9*C] (pad 1)."""
+    assert x.dtype == F16 and x.is_contiguous() and x.shape[0] == B * H * W
+    Cn = x.shape[1]
+    if out is None:
+        out = torch.empty((B * H * W, 9 * Cn), device=x.device, dtype=F16)
+    check(_lib.lib().ink_im2col3x3_f16(x.data_ptr(), B, H, W, Cn, out.data_ptr(), _stream()),
+          "ink_im2col3x3_f16")
+    return out
+
+
+def sam_pe_encode(coords01: torch.Tensor, gauss: torch.Tensor,
+                  add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[sin, cos](2*pi*((2c-1) @ G)) (+ add[n % n_add]) -> f32 [N, 2F]."""
+    assert coords01.dtype == F32 and coords01.is_contiguous() and coords01.shape[-1] == 2
+    assert gauss.dtype == F32 and gauss.is_contiguous() and gauss.shape[0] == 2
+    N, Fd = coords01.numel() // 2, gauss.shape[1]
+    out = torch.empty((N, 2 * Fd), device=coords01.device, dtype=F32)
+    n_add = 0
+    if add is not None:
+        assert add.dtype == F32 and add.is_contiguous() and add.shape[-1] == 2 * Fd
+        n_add = add.numel() // (2 * Fd)
+    check(_lib.lib().ink_sam_pe_encode(coords01.data_ptr(), gauss.data_ptr(), N, Fd, _p(add), n_add,
+                                       out.data_ptr(), _stream()), "ink_sam_pe_encode")
+    return out
+
+
+def sam_mask_logits(up: torch.Tensor, hyper: torch.Tensor, n: int, g: int) -> torch.Tensor:
+    """hyper[n,C] . up[(((b*g*g + tok)*4 + s1)*4 + s2), C] -> pixel-shuffled [n, 4g, 4g] f32."""
+    assert up.dtype == F32 and up.is_contiguous() and hyper.dtype == F32 and hyper.is_contiguous()
+    Cn = hyper.shape[1]
+    assert up.numel() == n * g * g * 16 * Cn
+    out = torch.empty((n, 4 * g, 4 * g), device=up.device, dtype=F32)
+    check(_lib.lib().ink_sam_mask_logits(up.data_ptr(), hyper.data_ptr(), n, g, Cn, out.data_ptr(),
+                                         _stream()), "ink_sam_mask_logits")
+    return out
+
+
+def sam_postprocess(low: torch.Tensor, L: int, input_hw: Tuple[int, int], orig_hw: Tuple[int, int],
+                    thr: float = 0.0, want_logits: bool = False):
+    """low [n,S,S] f32 -> uint8 masks [n, H, W] (and optionally the f32 logits)."""
+    assert low.dtype == F32 and low.is_contiguous() and low.dim() == 3
+    n, S, _ = low.shape
+    oh, ow = orig_hw
+    out = torch.empty((n, oh, ow), device=low.device, dtype=torch.uint8)
+    lg = torch.empty((n, oh, ow), device=low.device, dtype=F32) if want_logits else None
+    check(_lib.lib().ink_sam_postprocess(low.data_ptr(), n, S, L, input_hw[0], input_hw[1], oh, ow,
+                                         thr, out.data_ptr(), _p(lg), _stream()),
+          "ink_sam_postprocess")
+    return (out, lg) if want_logits else out

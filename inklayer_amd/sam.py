@@ -1,0 +1,451 @@
+"""SAM ViT-H segmentor on MI355X: host-side composition of the HIP kernels.
+
+Mirrors the reference surfaces for this path
+  * segment_anything.build_sam / SamPredictor  (SA/build_sam.py:55-107, SA/predictor.py:17-243)
+  * InkLayer.segmentor.sam.run_SAM              (InkLayer/segmentor/sam.py:16-43)
+with the same state_dict key names, so `sam_vit_h_4b8939.pth` drops in unchanged.
+
+Design (MI355X-first, not a translation of the nn.Module tree):
+  * tokens live as ONE f32 residual stream [B*4096, 1280]; every GEMM input is produced in
+    f16 by the kernel that precedes it (LayerNorm, GELU epilogue, attention), every GEMM
+    accumulates in f32 and applies bias / GELU / residual / window-unpartition in its epilogue;
+  * window partition + zero padding is a row-gather fused into LayerNorm; un-partition + crop
+    is a row-scatter fused into the proj GEMM epilogue (same int32 map for both);
+  * attention never materialises scores; the decomposed rel-pos bias rides inside the MFMA
+    accumulator (attention.hip);
+  * ConvTranspose2d k2s2 = a [C -> 4*C'] projection whose pixel shuffle is deferred to the
+    final mask-logit kernel; the two bilinear resizes + threshold are one kernel.
+No torch compute ops are used on the hot path — torch supplies memory, streams, copies.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+F16, F32 = torch.float16, torch.float32
+
+
+@dataclass
+class SamConfig:
+    """SA/build_sam.py:14-21,55-101 (defaults = ViT-H, the model InkLayer ships)."""
+    embed_dim: int = 1280
+    depth: int = 32
+    num_heads: int = 16
+    global_attn_indexes: Tuple[int, ...] = (7, 15, 23, 31)
+    window_size: int = 14
+    img_size: int = 1024
+    patch_size: int = 16
+    mlp_ratio: float = 4.0
+    prompt_embed_dim: int = 256
+    dec_depth: int = 2
+    dec_heads: int = 8
+    dec_mlp_dim: int = 2048
+    num_mask_tokens: int = 4
+    pixel_mean: Tuple[float, ...] = (123.675, 116.28, 103.53)
+    pixel_std: Tuple[float, ...] = (58.395, 57.12, 57.375)
+    mask_threshold: float = 0.0
+
+    @property
+    def grid(self) -> int:
+        return self.img_size // self.patch_size
+
+
+def preprocess_shape(h: int, w: int, L: int) -> Tuple[int, int]:
+    """ResizeLongestSide.get_preprocess_shape (SA/utils/transforms.py:93-102)."""
+    sc = L * 1.0 / max(h, w)
+    return int(h * sc + 0.5), int(w * sc + 0.5)
+
+
+def resize_longest_side(img: np.ndarray, L: int) -> np.ndarray:
+    """ResizeLongestSide.apply_image (SA/utils/transforms.py:26-31): PIL bilinear on the host
+    (kept on the CPU on purpose: it must match PIL's filter bit-for-bit)."""
+    from PIL import Image
+    nh, nw = preprocess_shape(img.shape[0], img.shape[1], L)
+    if (nh, nw) == img.shape[:2]:
+        return np.ascontiguousarray(img)
+    return np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+
+
+class SamEngine:
+    """Weights packed for the HIP kernels + preallocated activations for up to `max_batch` images."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[SamConfig] = None,
+                 device: str | torch.device = "cuda", max_batch: int = 1):
+        cfg = cfg or SamConfig()
+        self.cfg, self.dev = cfg, torch.device(device)
+        assert self.dev.type == "cuda", "the InkLayer segmentor runs on MI355X only"
+        D, g = cfg.embed_dim, cfg.grid
+        assert D // cfg.num_heads == 80 and g == 64 and cfg.window_size == 14, \
+            "HIP attention kernels are specialised for SAM's head_dim 80 / 64x64 grid / 14x14 windows"
+        E = cfg.prompt_embed_dim
+        assert E // cfg.dec_heads == 32 and (E // 2) // cfg.dec_heads == 16
+        self.T = g * g
+        self.scale = 80 ** -0.5
+        sd = state_dict
+        dev = self.dev
+
+        def h(name, shape=None):  # matrix -> f16 [N, K]
+            t = sd[name].detach().to(torch.float32)
+            if shape is not None:
+                t = t.reshape(shape)
+            return t.to(dev, F16).contiguous()
+
+        def f(name):  # vector / table -> f32
+            return sd[name].detach().to(dev, F32).contiguous()
+
+        self.w: Dict[str, torch.Tensor] = {}
+        w = self.w
+        P = cfg.patch_size
+        w["pe.w"] = h("image_encoder.patch_embed.proj.weight", (D, 3 * P * P))
+        w["pe.b"] = f("image_encoder.patch_embed.proj.bias")
+        w["pos"] = f("image_encoder.pos_embed").reshape(self.T, D).contiguous()
+        for i in range(cfg.depth):
+            p = f"image_encoder.blocks.{i}."
+            for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "attn.qkv.bias",
+                      "attn.proj.bias", "mlp.lin1.bias", "mlp.lin2.bias", "attn.rel_pos_h",
+                      "attn.rel_pos_w"):
+                w[f"b{i}.{n}"] = f(p + n)
+            for n in ("attn.qkv.weight", "attn.proj.weight", "mlp.lin1.weight", "mlp.lin2.weight"):
+                w[f"b{i}.{n}"] = h(p + n)
+        w["neck0.w"] = h("image_encoder.neck.0.weight", (E, D))
+        w["neck1.w"], w["neck1.b"] = f("image_encoder.neck.1.weight"), f("image_encoder.neck.1.bias")
+        # 3x3 conv weight re-laid out as [co][(ky,kx,ci)] to match the NHWC im2col
+        w["neck2.w"] = (sd["image_encoder.neck.2.weight"].detach().to(torch.float32)
+                        .permute(0, 2, 3, 1).reshape(E, 9 * E).to(dev, F16).contiguous())
+        w["neck3.w"], w["neck3.b"] = f("image_encoder.neck.3.weight"), f("image_encoder.neck.3.bias")
+
+        # ---- prompt encoder constants
+        w["gauss"] = f("prompt_encoder.pe_layer.positional_encoding_gaussian_matrix")
+        w["corner"] = torch.cat([f("prompt_encoder.point_embeddings.2.weight"),
+                                 f("prompt_encoder.point_embeddings.3.weight")], 0).contiguous()
+        w["no_mask"] = f("prompt_encoder.no_mask_embed.weight").reshape(-1).contiguous()
+        # dense positional encoding of the 64x64 grid (prompt_encoder.py:195-206): constant
+        ar = (torch.arange(g, dtype=torch.float32) + 0.5) / g
+        grid_xy = torch.stack([ar[None, :].expand(g, g), ar[:, None].expand(g, g)], -1).reshape(-1, 2)
+        self.dense_pe = ops.sam_pe_encode(grid_xy.contiguous().to(dev), w["gauss"])  # [T, E]
+
+        # ---- mask decoder
+        t = "mask_decoder.transformer."
+        def attn(dst, src, fuse_qkv=False, fuse_qk=False):
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                w[f"{dst}.{n}.w"] = h(f"{src}.{n}.weight")
+                w[f"{dst}.{n}.b"] = f(f"{src}.{n}.bias")
+            if fuse_qkv:
+                w[f"{dst}.qkv.w"] = torch.cat([w[f"{dst}.{n}.w"] for n in ("q_proj", "k_proj", "v_proj")]).contiguous()
+                w[f"{dst}.qkv.b"] = torch.cat([w[f"{dst}.{n}.b"] for n in ("q_proj", "k_proj", "v_proj")]).contiguous()
+            if fuse_qk:
+                w[f"{dst}.qk.w"] = torch.cat([w[f"{dst}.{n}.w"] for n in ("q_proj", "k_proj")]).contiguous()
+                w[f"{dst}.qk.b"] = torch.cat([w[f"{dst}.{n}.b"] for n in ("q_proj", "k_proj")]).contiguous()
+        for i in range(cfg.dec_depth):
+            p = f"{t}layers.{i}."
+            attn(f"d{i}.self", p + "self_attn", fuse_qkv=(i == 0), fuse_qk=(i > 0))
+            attn(f"d{i}.t2i", p + "cross_attn_token_to_image")
+            attn(f"d{i}.i2t", p + "cross_attn_image_to_token")
+            for n in ("norm1", "norm2", "norm3", "norm4"):
+                w[f"d{i}.{n}.w"], w[f"d{i}.{n}.b"] = f(p + n + ".weight"), f(p + n + ".bias")
+            w[f"d{i}.lin1.w"], w[f"d{i}.lin1.b"] = h(p + "mlp.lin1.weight"), f(p + "mlp.lin1.bias")
+            w[f"d{i}.lin2.w"], w[f"d{i}.lin2.b"] = h(p + "mlp.lin2.weight"), f(p + "mlp.lin2.bias")
+        attn("dfin", t + "final_attn_token_to_image")
+        w["dfin.norm.w"], w["dfin.norm.b"] = f(t + "norm_final_attn.weight"), f(t + "norm_final_attn.bias")
+        w["out_tok"] = torch.cat([f("mask_decoder.iou_token.weight"),
+                                  f("mask_decoder.mask_tokens.weight")], 0).contiguous()  # [5, E]
+        # ConvTranspose2d(k2,s2) as a projection to (dy,dx,co): W'[(dy*2+dx)*Co + co][ci]
+        u = "mask_decoder.output_upscaling."
+        w["up0.w"] = (sd[u + "0.weight"].detach().to(torch.float32).permute(2, 3, 1, 0)
+                      .reshape(4 * (E // 4), E).to(dev, F16).contiguous())
+        w["up0.b"] = f(u + "0.bias").repeat(4).contiguous()
+        w["up1.w"], w["up1.b"] = f(u + "1.weight"), f(u + "1.bias")
+        w["up3.w"] = (sd[u + "3.weight"].detach().to(torch.float32).permute(2, 3, 1, 0)
+                      .reshape(4 * (E // 8), E // 4).to(dev, F16).contiguous())
+        w["up3.b"] = f(u + "3.bias").repeat(4).contiguous()
+        for j in range(3):  # hyper-network of mask token 0 (multimask_output=False keeps mask 0 only)
+            w[f"hyp{j}.w"] = h(f"mask_decoder.output_hypernetworks_mlps.0.layers.{j}.weight")
+            w[f"hyp{j}.b"] = f(f"mask_decoder.output_hypernetworks_mlps.0.layers.{j}.bias")
+            w[f"iou{j}.w"] = h(f"mask_decoder.iou_prediction_head.layers.{j}.weight")
+            w[f"iou{j}.b"] = f(f"mask_decoder.iou_prediction_head.layers.{j}.bias")
+        # the last hyper layer has N = 32 outputs, the iou head N = 4: both fine for the GEMM (N % 4)
+
+        self._alloc(max_batch)
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self, B: int) -> None:
+        cfg, dev, T, D = self.cfg, self.dev, self.T, self.cfg.embed_dim
+        g, ws = cfg.grid, cfg.window_size
+        self.max_batch = B
+        nwin = -(-g // ws)                       # 5 windows per side (64 -> 70 padded)
+        self.nwin = nwin
+        Mw = nwin * nwin * ws * ws               # 4900 rows per image after padding
+        self.Mw = Mw
+        # window gather/scatter map (window_partition / window_unpartition, image_encoder.py:243-289)
+        r = torch.arange(B * Mw)
+        b, rr = r // Mw, r % Mw
+        win, pos = rr // (ws * ws), rr % (ws * ws)
+        y = (win // nwin) * ws + pos // ws
+        x = (win % nwin) * ws + pos % ws
+        m = torch.where((y < g) & (x < g), b * T + y * g + x, torch.full_like(r, -1))
+        self.win_map = m.to(torch.int32).to(dev)
+        P = cfg.patch_size
+        e = lambda *s, dt=F16: torch.empty(s, device=dev, dtype=dt)
+        self.buf_patches = e(B * T, 3 * P * P)
+        self.x = e(B * T, D, dt=F32)
+        self.y = e(B * Mw, D)
+        self.qkv = e(B * Mw, 3 * D)
+        self.att = e(B * Mw, D)
+        self.hid = e(B * T, int(D * cfg.mlp_ratio))
+        H = cfg.num_heads
+        self.rel_aug = e(B * nwin * nwin * H * ws * ws, 32)
+        self.rel_h = e(B * H * T, 64, dt=F32)
+        self.rel_w = e(B * H * T, 64, dt=F32)
+
+    # ------------------------------------------------------------------ encoder
+    def encode(self, images_u8: Sequence[torch.Tensor], chan_reverse: bool = False,
+               upto: Optional[int] = None) -> torch.Tensor:
+        """images_u8: resized HWC uint8 CUDA tensors (long side = img_size).
+        Returns the image embeddings as tokens [B, 4096, 256] f32 (NHWC; the reference's NCHW
+        `features` is `.permute(0, 2, 1).view(B, 256, 64, 64)`)."""
+        cfg, w, T, D = self.cfg, self.w, self.T, self.cfg.embed_dim
+        B = len(images_u8)
+        assert 1 <= B <= self.max_batch
+        H, Mw = cfg.num_heads, self.Mw
+        x = self.x[:B * T]
+        for b, img in enumerate(images_u8):
+            ops.sam_patchify(img, cfg.img_size, cfg.patch_size, cfg.pixel_mean, cfg.pixel_std,
+                             chan_reverse, self.buf_patches[b * T:(b + 1) * T])
+            ops.gemm(self.buf_patches[b * T:(b + 1) * T], w["pe.w"], w["pe.b"], residual=w["pos"],
+                     out=x[b * T:(b + 1) * T])
+        nblk = cfg.depth if upto is None else upto
+        for i in range(nblk):
+            k = f"b{i}."
+            if i in cfg.global_attn_indexes:
+                y = ops.layernorm_rows(x, w[k + "norm1.weight"], w[k + "norm1.bias"], 1e-6,
+                                       out=self.y[:B * T])
+                qkv = ops.gemm(y, w[k + "attn.qkv.weight"], w[k + "attn.qkv.bias"], out=self.qkv[:B * T])
+                q, kk, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+                rh, rw = ops.relpos_bias(q, w[k + "attn.rel_pos_h"], w[k + "attn.rel_pos_w"], S=cfg.grid,
+                                         n_batch=B, n_heads=H, head_dim=80, scale=self.scale,
+                                         out=(self.rel_h, self.rel_w))
+                o = ops.flash_attn(q, kk, v, n_batch=B, n_heads=H, head_dim=80, scale=self.scale,
+                                   rel_h=rh, rel_w=rw, grid_w=cfg.grid, out=self.att[:B * T])
+                ops.gemm(o, w[k + "attn.proj.weight"], w[k + "attn.proj.bias"], residual=x, out=x)
+            else:
+                wm = self.win_map[:B * Mw]
+                y = ops.layernorm_rows(x, w[k + "norm1.weight"], w[k + "norm1.bias"], 1e-6, gather=wm,
+                                       out=self.y[:B * Mw])
+                qkv = ops.gemm(y, w[k + "attn.qkv.weight"], w[k + "attn.qkv.bias"], out=self.qkv[:B * Mw])
+                q, kk, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+                nb = B * self.nwin * self.nwin
+                aug = ops.relpos_bias(q, w[k + "attn.rel_pos_h"], w[k + "attn.rel_pos_w"],
+                                      S=cfg.window_size, n_batch=nb, n_heads=H, head_dim=80,
+                                      scale=self.scale, out=self.rel_aug)
+                o = ops.flash_attn(q, kk, v, n_batch=nb, n_heads=H, head_dim=80, scale=self.scale,
+                                   rel_aug=aug, grid_w=cfg.window_size, out=self.att[:B * Mw])
+                ops.gemm(o, w[k + "attn.proj.weight"], w[k + "attn.proj.bias"], residual=x, row_map=wm,
+                         out=x)
+            y = ops.layernorm_rows(x, w[k + "norm2.weight"], w[k + "norm2.bias"], 1e-6, out=self.y[:B * T])
+            hd = ops.gemm(y, w[k + "mlp.lin1.weight"], w[k + "mlp.lin1.bias"], act="gelu",
+                          out=self.hid[:B * T])
+            ops.gemm(hd, w[k + "mlp.lin2.weight"], w[k + "mlp.lin2.bias"], residual=x, out=x)
+        if upto is not None:
+            return x.view(B, T, D)
+        # neck (image_encoder.py:88-104): 1x1 conv -> LN2d -> 3x3 conv -> LN2d, all on NHWC tokens
+        xh = ops.add_cvt_f16(x, out=self.y[:B * T])
+        n0 = ops.gemm(xh, w["neck0.w"])
+        n1 = ops.layernorm_rows(n0, w["neck1.w"], w["neck1.b"], 1e-6)
+        col = ops.im2col3x3(n1, B, cfg.grid, cfg.grid)
+        n2 = ops.gemm(col, w["neck2.w"])
+        emb = ops.layernorm_rows(n2, w["neck3.w"], w["neck3.b"], 1e-6, out_dtype=F32)
+        return emb.view(B, T, cfg.prompt_embed_dim)
+
+    # ------------------------------------------------------------------ decoder
+    def _dec_attn(self, name: str, q16, k16, v16, n: int, n_q: int, n_k: int, hd: int,
+                  residual: Optional[torch.Tensor], kv_rows=None, q_rows=None,
+                  pre_q=None, pre_k=None, pre_v=None) -> torch.Tensor:
+        """transformer.py Attention.forward (:218-240): projections + fused attention + out_proj.
+        pre_* let a caller pass already-projected operands (shared across boxes)."""
+        w = self.w
+        Hh = self.cfg.dec_heads
+        q = pre_q if pre_q is not None else ops.gemm(q16, w[name + ".q_proj.w"], w[name + ".q_proj.b"], out_dtype=F16)
+        k = pre_k if pre_k is not None else ops.gemm(k16, w[name + ".k_proj.w"], w[name + ".k_proj.b"], out_dtype=F16)
+        v = pre_v if pre_v is not None else ops.gemm(v16, w[name + ".v_proj.w"], w[name + ".v_proj.b"], out_dtype=F16)
+        a = ops.flash_attn(q, k, v, n_batch=n, n_heads=Hh, head_dim=hd, scale=1.0 / math.sqrt(hd),
+                           n_q=n_q, n_k=n_k, q_batch_rows=q_rows, kv_batch_rows=kv_rows)
+        return ops.gemm(a, w[name + ".out_proj.w"], w[name + ".out_proj.b"], residual=residual)
+
+    def decode(self, emb: torch.Tensor, boxes_input_frame: np.ndarray | torch.Tensor,
+               input_hw: Tuple[int, int], orig_hw: Tuple[int, int], want_logits: bool = False):
+        """One image: emb [4096, 256] f32 tokens, boxes [n, 4] xyxy in the resized-input frame
+        (host memory).  PromptEncoder + MaskDecoder(multimask_output=False) + postprocess.
+        Returns uint8 masks [n, H, W] on the GPU (+ low-res logits, iou, full logits if asked)."""
+        cfg, w, T, dev = self.cfg, self.w, self.T, self.dev
+        E, L, g = cfg.prompt_embed_dim, cfg.img_size, cfg.grid
+        boxes = torch.as_tensor(np.asarray(boxes_input_frame), dtype=torch.float32).reshape(-1, 4)
+        n = boxes.shape[0]
+        assert n > 0
+        NT = 5 + 2                                         # iou + 4 mask tokens + 2 box corners
+        # --- prompt encoder (_embed_boxes): host-side affine of 4n numbers, Fourier features on GPU
+        coords = ((boxes + 0.5).reshape(-1, 2) / float(L)).contiguous().to(dev)
+        sparse = ops.sam_pe_encode(coords, w["gauss"], add=w["corner"])           # [2n, E]
+        tokens = torch.empty((n, NT, E), device=dev, dtype=F32)
+        tokens[:, :5] = w["out_tok"]                       # plumbing copies (no math)
+        tokens[:, 5:] = sparse.view(n, 2, E)
+        qpe = tokens.view(n * NT, E)
+        zero_rows = torch.zeros(n, dtype=torch.int32, device=dev)
+
+        # --- image side, shared by all boxes: src = emb + no_mask_embed; key_pe = dense PE
+        keys0 = ops.add_f32(emb.reshape(T, E).contiguous(), w["no_mask"])          # [T, E]
+        kpe = self.dense_pe
+        queries = qpe
+        keys = None                                        # per-box keys [n*T, E] after layer 0
+        for i in range(cfg.dec_depth):
+            d = f"d{i}"
+            # (1) token self-attention
+            if i == 0:
+                t16 = ops.add_cvt_f16(queries)
+                qkv = ops.gemm(t16, w[d + ".self.qkv.w"], w[d + ".self.qkv.b"], out_dtype=F16)
+                queries = self._dec_attn(d + ".self", None, None, None, n, NT, NT, 32, None,
+                                         pre_q=qkv[:, :E], pre_k=qkv[:, E:2 * E], pre_v=qkv[:, 2 * E:])
+            else:
+                qk16 = ops.add_cvt_f16(queries, qpe)
+                qk = ops.gemm(qk16, w[d + ".self.qk.w"], w[d + ".self.qk.b"], out_dtype=F16)
+                queries = self._dec_attn(d + ".self", None, None, ops.add_cvt_f16(queries), n, NT, NT, 32,
+                                         queries, pre_q=qk[:, :E], pre_k=qk[:, E:])
+            queries = ops.layernorm_rows(queries, w[d + ".norm1.w"], w[d + ".norm1.b"], 1e-5, out_dtype=F32)
+            # (2) tokens -> image
+            q16 = ops.add_cvt_f16(queries, qpe)
+            if keys is None:
+                k16 = ops.add_cvt_f16(keys0, kpe)
+                v16 = ops.add_cvt_f16(keys0)
+                att = self._dec_attn(d + ".t2i", q16, k16, v16, n, NT, T, 16, queries, kv_rows=zero_rows)
+            else:
+                k16 = ops.add_cvt_f16(keys, kpe)
+                v16 = ops.add_cvt_f16(keys)
+                att = self._dec_attn(d + ".t2i", q16, k16, v16, n, NT, T, 16, queries)
+            queries = ops.layernorm_rows(att, w[d + ".norm2.w"], w[d + ".norm2.b"], 1e-5, out_dtype=F32)
+            # (3) token MLP
+            hmid = ops.gemm(ops.add_cvt_f16(queries), w[d + ".lin1.w"], w[d + ".lin1.b"], act="relu",
+                            out_dtype=F16)
+            queries = ops.layernorm_rows(ops.gemm(hmid, w[d + ".lin2.w"], w[d + ".lin2.b"], residual=queries),
+                                         w[d + ".norm3.w"], w[d + ".norm3.b"], 1e-5, out_dtype=F32)
+            # (4) image -> tokens (q = keys + key_pe = k16 from step 2)
+            tk16 = ops.add_cvt_f16(queries, qpe)
+            tv16 = ops.add_cvt_f16(queries)
+            if keys is None:
+                keys = ops.add_f32(torch.empty((n, T, E), device=dev, dtype=F32).zero_().view(n * T, E), keys0)
+                att = self._dec_attn(d + ".i2t", k16, tk16, tv16, n, T, NT, 16, keys, q_rows=zero_rows)
+            else:
+                att = self._dec_attn(d + ".i2t", k16, tk16, tv16, n, T, NT, 16, keys)
+            keys = ops.layernorm_rows(att, w[d + ".norm4.w"], w[d + ".norm4.b"], 1e-5, out_dtype=F32)
+        # final tokens -> image attention
+        q16 = ops.add_cvt_f16(queries, qpe)
+        att = self._dec_attn("dfin", q16, ops.add_cvt_f16(keys, kpe), ops.add_cvt_f16(keys), n, NT, T, 16,
+                             queries)
+        queries = ops.layernorm_rows(att, w["dfin.norm.w"], w["dfin.norm.b"], 1e-5, out_dtype=F32)
+        hs16 = ops.add_cvt_f16(queries).view(n, NT * E)
+
+        def mlp3(prefix: str, x16: torch.Tensor) -> torch.Tensor:
+            a = ops.gemm(x16, w[prefix + "0.w"], w[prefix + "0.b"], act="relu", out_dtype=F16)
+            a = ops.gemm(a, w[prefix + "1.w"], w[prefix + "1.b"], act="relu", out_dtype=F16)
+            return ops.gemm(a, w[prefix + "2.w"], w[prefix + "2.b"])
+
+        hyper = mlp3("hyp", hs16[:, E:2 * E])               # mask token 0 -> [n, 32]
+        iou = mlp3("iou", hs16[:, :E])[:, :1]               # iou token -> [n, 4] -> mask 0
+        # upscaling: ConvT(256->64) -> LN2d -> GELU -> ConvT(64->32) -> GELU, un-shuffled
+        u0 = ops.gemm(ops.add_cvt_f16(keys), w["up0.w"], w["up0.b"])             # [n*T, 4*64]
+        u1 = ops.layernorm_rows(u0.view(n * T * 4, E // 4), w["up1.w"], w["up1.b"], 1e-6, act="gelu")
+        u2 = ops.gemm(u1, w["up3.w"], w["up3.b"], act="gelu")                     # [n*T*4, 4*32]
+        low = ops.sam_mask_logits(u2, hyper.contiguous(), n, g)                   # [n, 256, 256]
+        res = ops.sam_postprocess(low, L, input_hw, orig_hw, cfg.mask_threshold, want_logits)
+        if want_logits:
+            return res[0], low, iou, res[1]
+        return res
+
+
+# ----------------------------------------------------------------------------------------
+# reference-shaped API
+# ----------------------------------------------------------------------------------------
+class SamPredictor:
+    """Same call surface as SA/predictor.py:17-243 for the box-prompt path InkLayer uses."""
+
+    def __init__(self, engine: SamEngine):
+        self.engine = engine
+        self.cfg = engine.cfg
+        self.reset_image()
+
+    def reset_image(self) -> None:
+        self.is_image_set = False
+        self.features = None
+        self.original_size = None
+        self.input_size = None
+
+    def set_image(self, image: np.ndarray, image_format: str = "RGB") -> None:
+        assert image_format in ("RGB", "BGR")
+        if image_format != "RGB":
+            image = image[..., ::-1]
+        rs = resize_longest_side(np.ascontiguousarray(image), self.cfg.img_size)
+        self.original_size = tuple(image.shape[:2])
+        self.input_size = tuple(rs.shape[:2])
+        dev_img = torch.from_numpy(np.ascontiguousarray(rs)).to(self.engine.dev)
+        self.features = self.engine.encode([dev_img])[0]
+        self.is_image_set = True
+
+    def apply_boxes(self, boxes: torch.Tensor) -> torch.Tensor:
+        """ResizeLongestSide.apply_boxes_torch (SA/utils/transforms.py:67-91), host side."""
+        oh, ow = self.original_size
+        nh, nw = preprocess_shape(oh, ow, self.cfg.img_size)
+        c = boxes.detach().cpu().reshape(-1, 2, 2).clone().to(torch.float)
+        c[..., 0] = c[..., 0] * (nw / ow)
+        c[..., 1] = c[..., 1] * (nh / oh)
+        return c.reshape(-1, 4)
+
+    def predict_torch(self, point_coords=None, point_labels=None, boxes: torch.Tensor = None,
+                      mask_input=None, multimask_output: bool = False, return_logits: bool = False):
+        if not self.is_image_set:
+            raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")
+        if point_coords is not None or mask_input is not None or multimask_output:
+            raise NotImplementedError("InkLayer only uses box prompts with multimask_output=False")
+        masks, low, iou, logits = self.engine.decode(self.features, boxes.detach().cpu(), self.input_size,
+                                                     self.original_size, want_logits=True)
+        n = masks.shape[0]
+        out = logits if return_logits else masks.bool()
+        return out.view(n, 1, *self.original_size), iou, low.view(n, 1, *low.shape[-2:])
+
+
+_ENGINES: Dict[str, SamEngine] = {}
+
+
+def build_sam(checkpoint: Optional[str] = None, state_dict=None, device="cuda",
+              max_batch: int = 1) -> SamEngine:
+    """SA/build_sam.py:55-107 (ViT-H).  Unlike the reference (which rebuilds the model and reloads
+    the 2.4 GB checkpoint on EVERY run_SAM call, InkLayer/segmentor/sam.py:23) the engine is cached
+    per checkpoint path and stays resident in HBM."""
+    if state_dict is None:
+        if checkpoint in _ENGINES:
+            return _ENGINES[checkpoint]
+        state_dict = torch.load(checkpoint, map_location="cpu", weights_only=True)
+    eng = SamEngine(state_dict, SamConfig(), device, max_batch)
+    if checkpoint is not None:
+        _ENGINES[checkpoint] = eng
+    return eng
+
+
+def run_SAM(image_pil, boxes_filt: torch.Tensor, sam_checkpoint: Optional[str] = None,
+            engine: Optional[SamEngine] = None) -> List[np.ndarray]:
+    """InkLayer/segmentor/sam.py:16-43.  Returns a list of HxW bool arrays, one per box.
+    Reference quirks kept: the RGB array goes through a channel reversal before being declared
+    "RGB" (:24-26).  Deviation (documented reference bug): zero boxes return []."""
+    if len(boxes_filt) == 0:
+        return []
+    eng = engine if engine is not None else build_sam(sam_checkpoint)
+    pred = SamPredictor(eng)
+    image = np.array(image_pil)[..., ::-1]                 # cv2.COLOR_BGR2RGB on an RGB array
+    pred.set_image(np.ascontiguousarray(image))
+    tb = pred.apply_boxes(boxes_filt)
+    masks, _, _ = pred.predict_torch(None, None, boxes=tb, multimask_output=False)
+    m = masks[:, 0].cpu().numpy()                          # ONE device->host copy for all boxes
+    return [m[i] for i in range(m.shape[0])]

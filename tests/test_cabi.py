@@ -40,7 +40,7 @@ def test_bad_arguments_are_rejected_without_launch():
     p.lda = p.ldw = 24
     p.ldc = 8
     assert l.ink_gemm_f16(ctypes.byref(p), None) == 1
-    assert l.ink_layernorm_rows(None, 0, None, None, 1e-6, None, 1, 4, None, None, 4, None) == 1
+    assert l.ink_layernorm_rows(None, 0, None, None, 1e-6, None, 1, 4, None, None, 4, 0, None) == 1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
