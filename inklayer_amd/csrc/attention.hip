@@ -248,24 +248,36 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
 
 // Decomposed relative-position terms, pre-divided by the softmax scale so that they can sit
 // next to q.k inside the accumulator:  rel_x[q, j] = (q . R_x[q_x - j + S - 1]) / scale.
-// One wave per (batch*head, query); lane = j.   SA/modeling/image_encoder.py:292-361.
-template <int HD>
+// SA/modeling/image_encoder.py:292-361.
+//
+// Work split so that the table row is WAVE-UNIFORM (scalar loads, SGPR operand of v_fma):
+// a wave handles the queries that share one grid coordinate f on the axis being processed
+// (axis 0: q_h == f, lanes run over q_w and batch*head; axis 1: q_w == f, lanes over q_h),
+// so every lane needs the same rows R[f - j + S - 1], j = 0..S-1.
+template <int HD, int S, bool AUG>
 __global__ __launch_bounds__(256) void relpos_kernel(const f16* __restrict__ Q, int64_t ldq,
                                                      const float* __restrict__ Rh,
-                                                     const float* __restrict__ Rw, int S,
-                                                     int n_batch, int n_heads, float inv_scale,
+                                                     const float* __restrict__ Rw, int n_batch,
+                                                     int n_heads, float inv_scale,
                                                      float* __restrict__ out_h,
                                                      float* __restrict__ out_w,
                                                      f16* __restrict__ out_aug) {
+  constexpr int GPW = 64 / S;                   // (batch,head) groups per wave: 1 (S=64) or 4 (S=14)
+  constexpr int NQ = S * S;
   const int lane = threadIdx.x & 63;
-  const int n_q = S * S;
-  const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (gw >= (int64_t)n_batch * n_heads * n_q) return;
-  const int q = (int)(gw % n_q);
-  const int bh = (int)(gw / n_q);
-  const int b = bh / n_heads, h = bh % n_heads;
-  const int qh = q / S, qw = q % S;
-  const f16* qp = Q + ((int64_t)b * n_q + q) * ldq + h * HD;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));  // wave id (provably uniform)
+  const int nbh = n_batch * n_heads;
+  const int bh_groups = (nbh + GPW - 1) / GPW;
+  if (wid >= 2 * S * bh_groups) return;                    // wave-uniform exit
+  const int axis = wid / (S * bh_groups);
+  const int f = (wid / bh_groups) % S;
+  const int bh = (wid % bh_groups) * GPW + lane / S;
+  const int o = lane % S;                                  // the other coordinate
+  const bool active = lane < GPW * S && bh < nbh;
+  const int bhc = active ? bh : 0;
+  const int b = bhc / n_heads, h = bhc % n_heads;
+  const int q = axis == 0 ? f * S + o : o * S + f;
+  const f16* qp = Q + ((int64_t)b * NQ + q) * ldq + h * HD;
   float qv[HD];
 #pragma unroll
   for (int i = 0; i < HD / 8; ++i) {
@@ -273,27 +285,42 @@ __global__ __launch_bounds__(256) void relpos_kernel(const f16* __restrict__ Q, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) qv[8 * i + j] = (float)v[j];
   }
-  if (out_aug) {  // window form: lanes 0..S-1 -> rel_h, S..2S-1 -> rel_w, rest zero; 32 f16 per query
-    float acc = 0.f;
-    if (lane < 2 * S) {
-      const bool isw = lane >= S;
-      const int j = isw ? lane - S : lane;
-      const float* r = (isw ? Rw + (int64_t)(qw - j + S - 1) * HD : Rh + (int64_t)(qh - j + S - 1) * HD);
+  const float* R = axis == 0 ? Rh : Rw;
+  if constexpr (AUG) {
+    // 32 f16 per query: cols [0,S) = rel_h, [S,2S) = rel_w, rest 0
+    f16* op = out_aug + ((int64_t)bhc * NQ + q) * 32 + axis * S;
+    float acc[S];
 #pragma unroll
-      for (int i = 0; i < HD; ++i) acc = fmaf(qv[i], r[i], acc);
-    }
-    if (lane < 32) out_aug[gw * 32 + lane] = (f16)(acc * inv_scale);
-  } else {  // global form: S == 64, lane = key row / key column
-    const float* rh = Rh + (int64_t)(qh - lane + S - 1) * HD;
-    const float* rw = Rw + (int64_t)(qw - lane + S - 1) * HD;
-    float ah = 0.f, aw = 0.f;
+    for (int j = 0; j < S; ++j) {
+      const float* r = R + (f - j + S - 1) * HD;          // uniform
+      float a = 0.f;
 #pragma unroll
-    for (int i = 0; i < HD; ++i) {
-      ah = fmaf(qv[i], rh[i], ah);
-      aw = fmaf(qv[i], rw[i], aw);
+      for (int i = 0; i < HD; ++i) a = fmaf(qv[i], r[i], a);
+      acc[j] = a * inv_scale;
     }
-    out_h[gw * 64 + lane] = ah * inv_scale;
-    out_w[gw * 64 + lane] = aw * inv_scale;
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < S; j += 2) *(f16x2*)(op + j) = (f16x2){(f16)acc[j], (f16)acc[j + 1]};
+      if (axis == 1) {
+#pragma unroll
+        for (int j = S; j < 32 - S; j += 2) *(f16x2*)(op + j) = (f16x2){(f16)0, (f16)0};
+      }
+    }
+  } else {
+    float* op = (axis == 0 ? out_h : out_w) + ((int64_t)bhc * NQ + q) * S;
+#pragma unroll 1
+    for (int j0 = 0; j0 < S; j0 += 4) {
+      f32x4 res;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float* r = R + (f - (j0 + jj) + S - 1) * HD;  // uniform
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < HD; ++i) a = fmaf(qv[i], r[i], a);
+        res[jj] = a * inv_scale;
+      }
+      if (active) *(f32x4*)(op + j0) = res;
+    }
   }
 }
 
@@ -344,9 +371,20 @@ extern "C" int ink_relpos_bias(const void* Q, int64_t ldq, const float* rel_pos_
   } else {
     INK_CHECK_ARG(S == 64 && out_h && out_w);
   }
-  const int64_t nw = (int64_t)n_batch * n_heads * S * S;
-  hipLaunchKernelGGL(relpos_kernel<80>, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0,
-                     (hipStream_t)stream, (const f16*)Q, ldq, rel_pos_h, rel_pos_w, S, n_batch,
-                     n_heads, 1.0f / scale, out_h, out_w, (f16*)out_aug_f16);
+  const f16* q = (const f16*)Q;
+  hipStream_t st = (hipStream_t)stream;
+  const int nbh = n_batch * n_heads;
+  if (out_aug_f16) {
+    INK_CHECK_ARG(S == 14);
+    const int waves = 2 * 14 * ((nbh + 3) / 4);
+    hipLaunchKernelGGL((relpos_kernel<80, 14, true>), dim3((waves + 3) / 4), dim3(256), 0, st, q, ldq,
+                       rel_pos_h, rel_pos_w, n_batch, n_heads, 1.0f / scale, out_h, out_w,
+                       (f16*)out_aug_f16);
+  } else {
+    const int waves = 2 * 64 * nbh;
+    hipLaunchKernelGGL((relpos_kernel<80, 64, false>), dim3((waves + 3) / 4), dim3(256), 0, st, q, ldq,
+                       rel_pos_h, rel_pos_w, n_batch, n_heads, 1.0f / scale, out_h, out_w,
+                       (f16*)nullptr);
+  }
   return ink_launch_status();
 }
