@@ -1,0 +1,109 @@
+"""Pins oracle/gdino_ref.py to the reference: tests/golden/gdino_small.npz was produced by the
+reference's own Swin-T / Transformer / MSDeformAttn / fusion / text-layer modules
+(tests/golden/make_gdino_golden.py) from the same seeded weights."""
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from oracle import gdino_ref, sam_ref
+
+GOLD = Path(__file__).parent / "golden" / "gdino_small.npz"
+SMALL = gdino_ref.GDinoConfig(enc_layers=2, dec_layers=2, num_queries=60)
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max()
+    assert err <= tol * max(1.0, np.abs(b).max()), (err, np.abs(b).max())
+
+
+def _close_rows(a, b, tol_p90, tol_max):
+    """Row-wise comparison for decoder outputs: with random weights a few queries are
+    ill-conditioned (the reference itself moves by 1e-3 there when its inputs move by 1e-6),
+    so the 90th percentile is held tight and the max loose."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    row = np.abs(a - b).max(axis=-1) / max(1.0, np.abs(b).max())
+    assert np.percentile(row, 90) <= tol_p90, np.percentile(row, 90)
+    assert row.max() <= tol_max, row.max()
+
+
+def _weights(seed):
+    sd = sam_ref.seeded_state_dict(gdino_ref.gdino_param_shapes(SMALL), seed)
+    for k in sd:
+        if k.endswith("gamma_v") or k.endswith("gamma_l"):
+            sd[k] = 0.3 * torch.ones_like(sd[k]) + 0.05 * sd[k]
+    return sd
+
+
+def test_text_masks_match_reference():
+    g = np.load(GOLD)
+    m, p = gdino_ref.text_masks_and_position_ids([int(t) for t in g["token_ids"]])
+    assert np.array_equal(m.numpy(), g["self_mask"])
+    assert np.array_equal(p.numpy(), g["position_ids"])
+    # "[CLS] a . b c . [SEP]"-like sentence: blocks {0},{1,2},{3,4,5},{6}
+    m, p = gdino_ref.text_masks_and_position_ids([101, 7, 1012, 8, 9, 1012, 102])
+    assert p.tolist() == [0, 0, 1, 0, 1, 2, 0]
+    assert m[3:6, 3:6].all() and not m[2, 3] and not m[0, 1]
+
+
+def test_msda_core_matches_reference_grid_sample_form():
+    g = np.load(GOLD)
+    out = gdino_ref.msda_core(torch.from_numpy(g["msda_value"]), [tuple(s) for s in g["msda_shapes"]],
+                              torch.from_numpy(g["msda_loc"]), torch.from_numpy(g["msda_w"]))
+    _close(out, g["msda_out"], 2e-6)
+
+
+@torch.no_grad()
+def test_detector_oracle_matches_reference_golden():
+    g = np.load(GOLD)
+    sd = _weights(int(g["seed"]))
+    st = {}
+    logits, boxes = gdino_ref.detector_forward(
+        sd, SMALL, torch.from_numpy(g["image"]), torch.from_numpy(g["encoded_text"]),
+        torch.from_numpy(g["self_mask"]), torch.from_numpy(g["position_ids"]), stages=st)
+    _close(st["feats"][0][0, ::8], g["feat1"], 2e-5)
+    _close(st["feats"][2][0, ::16], g["feat3"], 2e-5)
+    S0 = g["feat1"].shape[1] * g["feat1"].shape[2]
+    h0, w0 = g["feat1"].shape[1:]
+    lvl = sd["transformer.level_embed"]
+    pos0 = (st["pos"][0, :S0] - lvl[0]).t().reshape(256, h0, w0)
+    _close(pos0[::16], g["pos0"], 1e-5)
+    h3, w3 = g["pos3"].shape[1:]
+    pos3 = (st["pos"][0, -h3 * w3:] - lvl[3]).t().reshape(256, h3, w3)
+    _close(pos3[::16], g["pos3"], 1e-5)
+    _close(st["src"][0, -h3 * w3:].t().reshape(256, h3, w3)[::8], g["src3"], 2e-5)
+    _close(st["memory_text"][0], g["memory_text"], 5e-5)
+    _close(st["refs"][0][0], g["ref_init"], 5e-5)
+    _close_rows(st["hs"][-1][0], g["hs_last"], 5e-5, 2e-3)
+    _close(st["refs"][-2][0], g["ref_last"], 1e-4)
+    _close_rows(boxes[0], g["pred_boxes"], 5e-5, 2e-3)
+    _close_rows(logits[0], g["pred_logits"], 5e-5, 2e-3)
+    assert bool(g["logits_pad_is_neginf"])
+
+
+def test_resize_shape_and_postprocess():
+    # get_size_with_aspect_ratio (GD/datasets/transforms.py:90-108)
+    assert gdino_ref.resize_shape(1024, 1024) == (800, 800)
+    assert gdino_ref.resize_shape(750, 750) == (800, 800)
+    assert gdino_ref.resize_shape(2000, 1000) == (666, 1333)     # max_size clamp
+    assert gdino_ref.resize_shape(640, 480) == (800, 1066)
+    lg = torch.full((5, 4), -10.0)
+    lg[1, 2] = 3.0
+    lg[4, 0] = -1.0   # sigmoid = 0.269 > 0.2
+    bx = torch.tensor([[0.5, 0.5, 0.2, 0.4]] * 5)
+    xyxy, sc = gdino_ref.postprocess_detections(lg, bx)
+    assert xyxy.shape == (2, 4) and xyxy.dtype == np.float64
+    assert np.allclose(xyxy[0], [0.4, 0.3, 0.6, 0.7])
+    assert np.allclose(sc, torch.sigmoid(torch.tensor([3.0, -1.0])).numpy())
+
+
+def test_param_inventory_swin_t():
+    shapes = gdino_ref.gdino_param_shapes(gdino_ref.GDinoConfig())
+    n_swin = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith("backbone.0."))
+    n_tr = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith("transformer."))
+    # Swin-T 27.52 M, Transformer 33.26 M (incl. enc_out_bbox_embed, excl. shared bbox_embed)
+    assert abs(n_swin - 27.52e6) < 0.02e6, n_swin
+    assert abs(n_tr - 33.26e6) < 0.15e6, n_tr
