@@ -88,7 +88,7 @@ def test_resize_shape_and_postprocess():
     # get_size_with_aspect_ratio (GD/datasets/transforms.py:90-108)
     assert gdino_ref.resize_shape(1024, 1024) == (800, 800)
     assert gdino_ref.resize_shape(750, 750) == (800, 800)
-    assert gdino_ref.resize_shape(2000, 1000) == (666, 1333)     # max_size clamp
+    assert gdino_ref.resize_shape(2000, 1000) == (666, 1332)     # max_size clamp: int(666*2000/1000)
     assert gdino_ref.resize_shape(640, 480) == (800, 1066)
     lg = torch.full((5, 4), -10.0)
     lg[1, 2] = 3.0
