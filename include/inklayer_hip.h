@@ -93,7 +93,11 @@ int ink_add_f32(const float* a, const float* b, int64_t n_b, float* out, int64_t
  *              f32 [n_batch*n_heads, n_q, 64] as produced by ink_relpos_bias.
  * bias_mode 2: SAM 14x14 windows: rel_aug f16 [n_batch*n_heads, n_q, 32] from ink_relpos_bias
  *              (cols 0..S-1 = rel_h, S..2S-1 = rel_w); grid_w = S.
- * Supported head_dim: 80 (modes 0,1,2), 32 and 16 (mode 0).
+ * bias_mode 3: Swin windows (GD/.../swin_transformer.py:148-167), n_q, n_k <= 64: dense_bias f32
+ *              [n_heads, n_q, 64] (relative_position_bias_table gathered by relative_position_index)
+ *              + optional dense_mask f32 [n_mask, n_q, 64] (the 0/-100 SW-MSA mask; batch entry b
+ *              uses mask b % n_mask).  Both are PRE-DIVIDED by `scale` and row-padded to 64.
+ * Supported head_dim: 80 (modes 0,1,2), 32 (modes 0,3) and 16 (mode 0).
  * q_batch_rows / kv_batch_rows (int32 [n_batch], optional): first row of batch entry b in Q/O and
  * in K/V; NULL means b*n_q and b*n_k.  Lets many batch entries share one K/V (or Q) block, e.g.
  * SAM decoder layer 0 where the image keys are identical for all boxes of an image.
@@ -110,6 +114,8 @@ typedef struct InkAttn {
   const int32_t* kv_batch_rows;
   const float* rel_h; const float* rel_w;         /* mode 1 */
   const void* rel_aug;                            /* mode 2 */
+  const float* dense_bias; const float* dense_mask; /* mode 3 */
+  int32_t n_mask; int32_t _pad;
 } InkAttn;
 int ink_flash_attn(const InkAttn* p, void* stream);
 
@@ -157,6 +163,89 @@ int ink_sam_mask_logits(const float* up, const float* hyper, int32_t n, int32_t 
 int ink_sam_postprocess(const float* low, int32_t n, int32_t S, int32_t L, int32_t in_h,
                         int32_t in_w, int32_t out_h, int32_t out_w, float thr, void* out_u8,
                         float* out_logits, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Multi-scale deformable attention forward — the reference's ONLY native op.
+ * ink_ms_deform_attn_forward mirrors groundingdino._C.ms_deform_attn_forward
+ * (GD/models/GroundingDINO/csrc/vision.cpp:53-56, MsDeformAttn/ms_deform_attn.h:21-40,
+ * ms_deform_attn_cuda.cu:21-81): value f32 [B,S,M,C], spatial_shapes int64 [L,2] (h,w),
+ * level_start_index int64 [L], sampling_loc f32 [B,Q,M,L,P,2] (x,y in [0,1]), attn_weight f32
+ * [B,Q,M,L,P], im2col_step (only validated: B % min(B, step) == 0) -> out f32 [B,Q,M*C].
+ * The two int64 arrays are HOST pointers here (the reference reads them on the device; they are
+ * 8 numbers known to the caller).  C must be 32.
+ * --------------------------------------------------------------------- */
+int ink_ms_deform_attn_forward(const float* value, const int64_t* spatial_shapes_host,
+                               const int64_t* level_start_index_host, const float* sampling_loc,
+                               const float* attn_weight, int32_t B, int32_t S, int32_t M, int32_t C,
+                               int32_t Q, int32_t L, int32_t P, int32_t im2col_step, float* out,
+                               void* stream);
+
+/* Pipeline form of the same op (MultiScaleDeformableAttention.forward, ms_deform_attn.py:282-352,
+ * minus the three Linear layers): value f16 [B,S,8,32]; proj f32 [B*Q, ldp] with columns
+ * [0,256) = sampling_offsets(query) as (head,level,point,xy) and [256,384) = attention_weights(query)
+ * as (head,level,point); softmax over the 16 (level,point) logits, the sampling-location arithmetic
+ * (2-d refs: ref + off/(W_l,H_l); 4-d refs: ref_xy + off/4 * ref_wh * 0.5) and the bilinear
+ * gather are fused; out f16 [B*Q, 256].  ref: f32, element (b,q) at b*ref_b_stride + q*ref_q_stride,
+ * the same for every level (valid_ratios == 1).  shapes_host: int32 [4,2] (h,w), HOST pointer. */
+int ink_msda_fused(const void* value_f16, const float* proj, int64_t ldp, const float* ref,
+                   int32_t ref_dim, int64_t ref_q_stride, int64_t ref_b_stride,
+                   const int32_t* shapes_host, int32_t B, int32_t S, int32_t Q, void* out_f16,
+                   void* stream);
+
+/* load_image normalisation (GD/util/inference.py:40-49: /255, -mean, /std) + Swin PatchEmbed 4x4/s4
+ * gather (swin_transformer.py:480-489): u8 HWC [h,w,3] -> f16 [ceil(h/4)*ceil(w/4), 64]
+ * (48 real columns c*16+ky*4+kx, 16 zero columns).  mean3/std3 are HOST pointers. */
+int ink_swin_patchify(const void* image_u8, int32_t h, int32_t w, const float* mean3,
+                      const float* std3, void* out_f16, void* stream);
+
+/* PatchMerging (swin_transformer.py:314-340): out[r] = LN(concat of the 4 source rows gather4[r][0..3])
+ * in f16 [rows, 4C]; index -1 = zero row (odd-size padding).  C <= 1024. */
+int ink_layernorm_merge4(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                         const int32_t* gather4, int32_t rows, int32_t C, void* out_f16, void* stream);
+
+/* nn.GroupNorm(G, C) on NHWC tokens x f32 [B,T,C] (input_proj, groundingdino.py:121-151);
+ * stats_ws: f32 [B*G*2] scratch; out f32, batch b written at out + b*out_batch_stride. */
+int ink_groupnorm_nhwc(const float* x, int32_t B, int32_t T, int32_t C, int32_t G, const float* gamma,
+                       const float* beta, float eps, float* stats_ws, float* out,
+                       int64_t out_batch_stride, void* stream);
+
+/* Row gather of f32 rows (batch b reads row idx[b*idx_batch_stride + r] of x + b*x_batch_rows rows;
+ * -1 -> zeros) into f16 and/or f32 [B*rows_per_batch, C]: masked_fill of invalid proposals
+ * (GD/.../utils.py:111-113) and the top-k gathers of transformer.py:302-316. */
+int ink_gather_rows(const float* x, int64_t ldx, int64_t x_batch_rows, const int32_t* idx,
+                    int64_t idx_batch_stride, int32_t rows_per_batch, int32_t B, int32_t C,
+                    void* out_f16, float* out_f32, void* stream);
+
+/* BiMultiHeadAttention core (GD/.../fuse_modules.py:168-240), both directions, no score matrix in
+ * HBM beyond [B,S,4,T] f32:  QV f16 [B*S, 2E] = [v_proj(v) | values_v_proj(v)],
+ * KL f16 [B*T, 2E] = [l_proj(l) | values_l_proj(l)], E = 1024 (4 heads x 256), T <= 4.
+ * out_v f16 [B*S, E] (softmax over text), out_l f16 [B*T, E] (softmax over image tokens).
+ * Workspaces: scores_ws f32 [B*S*4*T], stats_ws f32 [B*4*T*2], partial_ws f32 [B*4*ceil(S/chunk)*T*256]. */
+int ink_biattn_fusion(const void* QV_f16, const void* KL_f16, int32_t B, int32_t S, int32_t T, int32_t E,
+                      float scale, float* scores_ws, float* stats_ws, float* partial_ws, int32_t chunk,
+                      void* out_v_f16, void* out_l_f16, void* stream);
+
+/* softmax(scale q k^T [+ blocked -> -inf]) v against n_k <= 16 keys; f16 rows, head h at columns
+ * [h*hd,(h+1)*hd), hd in {16,32,64}; blocked: u8 [n_q, n_k] (1 = not allowed) or NULL.
+ * Text self-attention (transformer_vanilla.py:114-116) and decoder text cross-attention
+ * (transformer.py:893-900). */
+int ink_attn_fewkeys(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                     int32_t B, int32_t n_q, int32_t n_k, int32_t n_heads, int32_t head_dim, float scale,
+                     const uint8_t* blocked, void* O, int64_t ldo, void* stream);
+
+/* Two-stage query selection (transformer.py:293-300): indices of the K largest max_t logits[b,s,t],
+ * descending, ties -> lower index.  logits f32 [B,S,T], S <= 16384; out_idx int32 [B,K]. */
+int ink_topk_rowmax(const float* logits, int32_t B, int32_t S, int32_t T, int32_t K, int32_t* out_idx,
+                    float* out_val, void* stream);
+
+/* gen_sineembed_for_position (GD/.../utils.py:204-230) for boxes ref f32 [N,4] -> f16 [N,512];
+ * dim_t f32 [128] = 10000^(2*(i//2)/128). */
+int ink_sine_embed4(const float* ref, const float* dim_t, int32_t N, void* out_f16, void* stream);
+
+/* out = sigmoid(delta[:, :4] + inverse_sigmoid(ref))  (transformer.py:716-722, util/misc.py:704-708);
+ * ref_is_logit != 0: ref is already un-sigmoided (two-stage anchors, transformer.py:296-305). */
+int ink_box_refine(const float* delta, int64_t ldd, const float* ref, int32_t N, int32_t ref_is_logit,
+                   float* out, void* stream);
 
 #ifdef __cplusplus
 }

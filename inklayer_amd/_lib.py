@@ -33,6 +33,7 @@ class InkAttn(C.Structure):
         ("head_dim", c_int), ("scale", c_float), ("bias_mode", c_int), ("grid_w", c_int),
         ("q_batch_rows", c_void_p), ("kv_batch_rows", c_void_p),
         ("rel_h", c_void_p), ("rel_w", c_void_p), ("rel_aug", c_void_p),
+        ("dense_bias", c_void_p), ("dense_mask", c_void_p), ("n_mask", c_int), ("_pad", c_int),
     ]
 
 
@@ -52,6 +53,24 @@ SIGNATURES = {
     "ink_sam_mask_logits": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ink_sam_postprocess": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                             c_void_p, c_void_p, c_void_p],
+    "ink_ms_deform_attn_forward": [c_void_p, C.POINTER(c_i64), C.POINTER(c_i64), c_void_p, c_void_p, c_int,
+                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ink_msda_fused": [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_i64, c_i64, C.POINTER(c_int), c_int,
+                       c_int, c_int, c_void_p, c_void_p],
+    "ink_swin_patchify": [c_void_p, c_int, c_int, C.POINTER(c_float), C.POINTER(c_float), c_void_p, c_void_p],
+    "ink_layernorm_merge4": [c_void_p, c_i64, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p,
+                             c_void_p],
+    "ink_groupnorm_nhwc": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
+                           c_void_p, c_i64, c_void_p],
+    "ink_gather_rows": [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p,
+                        c_void_p],
+    "ink_biattn_fusion": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                          c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "ink_attn_fewkeys": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int,
+                         c_float, c_void_p, c_void_p, c_i64, c_void_p],
+    "ink_topk_rowmax": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "ink_sine_embed4": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "ink_box_refine": [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "ink_relpos_bias": [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                         c_void_p, c_void_p, c_void_p, c_void_p],
 }

@@ -71,8 +71,22 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
     qf[NQKB] = *(const f16x8*)(R + 8 * hh);
     qf[NQKB + 1] = *(const f16x8*)(R + 16 + 8 * hh);
   }
-  float relw[2][16];
+  float relw[2][16];   // mode 1: rel_w of this query; mode 3: the whole (bias + mask) row
   const float* RH = nullptr;
+  if constexpr (MODE == 3) {
+    // rows padded to 64 floats, pre-divided by scale: bias[h][q][64] + mask[b % n_mask][q][64]
+    const float* bp = p.dense_bias + ((int64_t)h * p.n_q + q_c) * 64;
+    const float* mp = p.dense_mask ? p.dense_mask + ((int64_t)(b % p.n_mask) * p.n_q + q_c) * 64 : nullptr;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = *(const f32x4*)(bp + sub * 32 + 8 * g + 4 * hh);
+        if (mp) v += *(const f32x4*)(mp + sub * 32 + 8 * g + 4 * hh);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) relw[sub][4 * g + r] = v[r];
+      }
+  }
   if constexpr (MODE == 1) {
     const float* RW = p.rel_w + ((int64_t)bh * p.n_q + q_c) * 64;
     RH = p.rel_h + ((int64_t)bh * p.n_q + q_c) * 64;
@@ -168,6 +182,12 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
       for (int r = 0; r < 16; ++r) {
         s0[r] = relw[0][r] + rh;
         s1[r] = relw[1][r] + rh;
+      }
+    } else if constexpr (MODE == 3) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = relw[0][r];
+        s1[r] = relw[1][r];
       }
     } else {
 #pragma unroll
@@ -351,6 +371,9 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
     INK_FA(80, 0, 4);
   } else if (p.head_dim == 32 && p.bias_mode == 0) {
     if (p.n_q <= 32) { INK_FA(32, 0, 1) } else { INK_FA(32, 0, 4) }
+  } else if (p.head_dim == 32 && p.bias_mode == 3) {
+    INK_CHECK_ARG(p.dense_bias && p.n_k <= 64 && p.n_q <= 64 && (!p.dense_mask || p.n_mask > 0));
+    INK_FA(32, 3, 2);
   } else if (p.head_dim == 16 && p.bias_mode == 0) {
     if (p.n_q <= 32) { INK_FA(16, 0, 1) } else { INK_FA(16, 0, 4) }
   } else {

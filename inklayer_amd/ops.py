@@ -128,6 +128,7 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: in
                head_dim: int, scale: float, n_q: Optional[int] = None, n_k: Optional[int] = None,
                rel_h: Optional[torch.Tensor] = None, rel_w: Optional[torch.Tensor] = None,
                rel_aug: Optional[torch.Tensor] = None, grid_w: int = 0,
+               dense_bias: Optional[torch.Tensor] = None, dense_mask: Optional[torch.Tensor] = None,
                q_batch_rows: Optional[torch.Tensor] = None,
                kv_batch_rows: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -156,7 +157,13 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: in
         if t is not None:
             assert t.dtype == torch.int32 and t.numel() == n_batch and t.is_cuda
             setattr(p, name, t.data_ptr())
-    if rel_aug is not None:
+    if dense_bias is not None:
+        assert dense_bias.dtype == F32 and dense_bias.is_contiguous() and dense_bias.shape == (n_heads, n_q, 64)
+        p.bias_mode, p.dense_bias = 3, dense_bias.data_ptr()
+        if dense_mask is not None:
+            assert dense_mask.dtype == F32 and dense_mask.is_contiguous() and dense_mask.shape[1:] == (n_q, 64)
+            p.dense_mask, p.n_mask = dense_mask.data_ptr(), dense_mask.shape[0]
+    elif rel_aug is not None:
         assert rel_aug.dtype == F16 and rel_aug.is_contiguous()
         p.bias_mode, p.rel_aug = 2, rel_aug.data_ptr()
     elif rel_h is not None:
@@ -257,3 +264,144 @@ def sam_postprocess(low: torch.Tensor, L: int, input_hw: Tuple[int, int], orig_h
                                          thr, out.data_ptr(), _p(lg), _stream()),
           "ink_sam_postprocess")
     return (out, lg) if want_logits else out
+
+
+# ---------------------------------------------------------------------------------------------
+# GroundingDINO-side ops
+# ---------------------------------------------------------------------------------------------
+def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes, level_start_index,
+                           sampling_loc: torch.Tensor, attn_weight: torch.Tensor,
+                           im2col_step: int = 64) -> torch.Tensor:
+    """Same argument list as groundingdino._C.ms_deform_attn_forward (GD/.../csrc/vision.cpp:53-56)."""
+    assert value.dtype == F32 and value.is_contiguous() and value.is_cuda
+    assert sampling_loc.dtype == F32 and sampling_loc.is_contiguous()
+    assert attn_weight.dtype == F32 and attn_weight.is_contiguous()
+    B, S, M, Cn = value.shape
+    _, Q, _, L, P, _ = sampling_loc.shape
+    ss = [int(v) for v in torch.as_tensor(spatial_shapes).reshape(-1).tolist()]
+    ls = [int(v) for v in torch.as_tensor(level_start_index).reshape(-1).tolist()]
+    out = torch.empty((B, Q, M * Cn), device=value.device, dtype=F32)
+    check(_lib.lib().ink_ms_deform_attn_forward(
+        value.data_ptr(), (C.c_int64 * len(ss))(*ss), (C.c_int64 * len(ls))(*ls), sampling_loc.data_ptr(),
+        attn_weight.data_ptr(), B, S, M, Cn, Q, L, P, im2col_step, out.data_ptr(), _stream()),
+        "ink_ms_deform_attn_forward")
+    return out
+
+
+def msda_fused(value16: torch.Tensor, proj: torch.Tensor, ref: torch.Tensor, shapes: Sequence[Tuple[int, int]],
+               B: int, Q: int, ref_batched: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """value16 f16 [B*S, 256]; proj f32 [B*Q, >=384]; ref f32 [Q, d] (shared) or [B*Q, d], d in {2,4}."""
+    assert value16.dtype == F16 and value16.is_contiguous() and proj.dtype == F32 and proj.stride(1) == 1
+    assert ref.dtype == F32 and ref.is_contiguous()
+    S = value16.shape[0] // B
+    d = ref.shape[-1]
+    if out is None:
+        out = torch.empty((B * Q, 256), device=value16.device, dtype=F16)
+    flat = [v for hw in shapes for v in hw]
+    check(_lib.lib().ink_msda_fused(value16.data_ptr(), proj.data_ptr(), proj.stride(0), ref.data_ptr(), d, d,
+                                    Q * d if ref_batched else 0, (C.c_int32 * 8)(*flat), B, S, Q,
+                                    out.data_ptr(), _stream()), "ink_msda_fused")
+    return out
+
+
+def swin_patchify(image_u8: torch.Tensor, mean: Sequence[float], std: Sequence[float], out: torch.Tensor):
+    assert image_u8.dtype == torch.uint8 and image_u8.is_cuda and image_u8.is_contiguous()
+    h, w, c = image_u8.shape
+    assert c == 3 and out.dtype == F16 and out.is_contiguous() and out.numel() == -(-h // 4) * -(-w // 4) * 64
+    check(_lib.lib().ink_swin_patchify(image_u8.data_ptr(), h, w, (C.c_float * 3)(*mean), (C.c_float * 3)(*std),
+                                       out.data_ptr(), _stream()), "ink_swin_patchify")
+    return out
+
+
+def layernorm_merge4(x: torch.Tensor, gamma, beta, eps: float, gather4: torch.Tensor) -> torch.Tensor:
+    assert x.dtype == F32 and x.stride(1) == 1 and gather4.dtype == torch.int32 and gather4.is_contiguous()
+    rows, Cn = gather4.shape[0], x.shape[1]
+    out = torch.empty((rows, 4 * Cn), device=x.device, dtype=F16)
+    check(_lib.lib().ink_layernorm_merge4(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), eps,
+                                          gather4.data_ptr(), rows, Cn, out.data_ptr(), _stream()),
+          "ink_layernorm_merge4")
+    return out
+
+
+def groupnorm_nhwc(x: torch.Tensor, B: int, T: int, G: int, gamma, beta, eps: float, out: torch.Tensor,
+                   out_batch_stride: int) -> None:
+    """x f32 [B*T, C] -> out (f32) at out + b*out_batch_stride + t*C (writes into the level's slice of
+    the flattened multi-scale source)."""
+    assert x.dtype == F32 and x.is_contiguous() and out.dtype == F32
+    Cn = x.shape[1]
+    ws = torch.empty(B * G * 2, device=x.device, dtype=F32)
+    check(_lib.lib().ink_groupnorm_nhwc(x.data_ptr(), B, T, Cn, G, gamma.data_ptr(), beta.data_ptr(), eps,
+                                        ws.data_ptr(), out.data_ptr(), out_batch_stride, _stream()),
+          "ink_groupnorm_nhwc")
+
+
+def gather_rows(x: torch.Tensor, idx: torch.Tensor, B: int, rows_per_batch: int, *, x_batch_rows: int,
+                idx_batch_stride: int, out_dtype=F16) -> torch.Tensor:
+    assert x.dtype == F32 and x.stride(1) == 1 and idx.dtype == torch.int32 and idx.is_cuda
+    Cn = x.shape[1]
+    out = torch.empty((B * rows_per_batch, Cn), device=x.device, dtype=out_dtype)
+    oh = out.data_ptr() if out_dtype == F16 else None
+    of = out.data_ptr() if out_dtype == F32 else None
+    check(_lib.lib().ink_gather_rows(x.data_ptr(), x.stride(0), x_batch_rows, idx.data_ptr(), idx_batch_stride,
+                                     rows_per_batch, B, Cn, oh, of, _stream()), "ink_gather_rows")
+    return out
+
+
+def biattn_fusion(qv16: torch.Tensor, kl16: torch.Tensor, B: int, S: int, T: int, scale: float,
+                  chunk: int = 128):
+    assert qv16.dtype == F16 and qv16.is_contiguous() and kl16.dtype == F16 and kl16.is_contiguous()
+    E = qv16.shape[1] // 2
+    dev = qv16.device
+    nchunk = -(-S // chunk)
+    scores = torch.empty(B * S * 4 * T, device=dev, dtype=F32)
+    stats = torch.empty(B * 4 * T * 2, device=dev, dtype=F32)
+    partial = torch.empty(B * 4 * nchunk * T * 256, device=dev, dtype=F32)
+    out_v = torch.empty((B * S, E), device=dev, dtype=F16)
+    out_l = torch.empty((B * T, E), device=dev, dtype=F16)
+    check(_lib.lib().ink_biattn_fusion(qv16.data_ptr(), kl16.data_ptr(), B, S, T, E, scale, scores.data_ptr(),
+                                       stats.data_ptr(), partial.data_ptr(), chunk, out_v.data_ptr(),
+                                       out_l.data_ptr(), _stream()), "ink_biattn_fusion")
+    return out_v, out_l
+
+
+def attn_fewkeys(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, B: int, n_heads: int, head_dim: int,
+                 scale: float, blocked: Optional[torch.Tensor] = None) -> torch.Tensor:
+    for t in (q, k, v):
+        assert t.dtype == F16 and t.dim() == 2 and t.stride(1) == 1
+    n_q, n_k = q.shape[0] // B, k.shape[0] // B
+    out = torch.empty((B * n_q, n_heads * head_dim), device=q.device, dtype=F16)
+    if blocked is not None:
+        assert blocked.dtype == torch.uint8 and blocked.is_contiguous() and blocked.shape == (n_q, n_k)
+    check(_lib.lib().ink_attn_fewkeys(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
+                                      v.stride(0), B, n_q, n_k, n_heads, head_dim, scale, _p(blocked),
+                                      out.data_ptr(), out.stride(0), _stream()), "ink_attn_fewkeys")
+    return out
+
+
+def topk_rowmax(logits: torch.Tensor, K: int, want_values: bool = False):
+    """logits f32 [B,S,T] -> int32 [B,K] indices of the K largest row maxima (descending, stable)."""
+    assert logits.dtype == F32 and logits.is_contiguous() and logits.dim() == 3
+    B, S, T = logits.shape
+    idx = torch.empty((B, K), device=logits.device, dtype=torch.int32)
+    val = torch.empty((B, K), device=logits.device, dtype=F32) if want_values else None
+    check(_lib.lib().ink_topk_rowmax(logits.data_ptr(), B, S, T, K, idx.data_ptr(), _p(val), _stream()),
+          "ink_topk_rowmax")
+    return (idx, val) if want_values else idx
+
+
+def sine_embed4(ref: torch.Tensor, dim_t: torch.Tensor) -> torch.Tensor:
+    assert ref.dtype == F32 and ref.is_contiguous() and ref.shape[-1] == 4 and dim_t.numel() == 128
+    N = ref.numel() // 4
+    out = torch.empty((N, 512), device=ref.device, dtype=F16)
+    check(_lib.lib().ink_sine_embed4(ref.data_ptr(), dim_t.data_ptr(), N, out.data_ptr(), _stream()),
+          "ink_sine_embed4")
+    return out
+
+
+def box_refine(delta: torch.Tensor, ref: torch.Tensor, ref_is_logit: bool = False) -> torch.Tensor:
+    assert delta.dtype == F32 and delta.stride(1) == 1 and ref.dtype == F32 and ref.is_contiguous()
+    N = ref.numel() // 4
+    out = torch.empty_like(ref)
+    check(_lib.lib().ink_box_refine(delta.data_ptr(), delta.stride(0), ref.data_ptr(), N, int(ref_is_logit),
+                                    out.data_ptr(), _stream()), "ink_box_refine")
+    return out

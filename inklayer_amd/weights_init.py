@@ -99,3 +99,93 @@ def sam_param_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
 
 def random_sam_state_dict(cfg, device, seed: int = 0) -> Dict[str, torch.Tensor]:
     return _fill(sam_param_shapes(cfg), device, seed)
+
+
+def gdino_param_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
+    """Parameter names/shapes of the GroundingDINO Swin-T model minus BERT/feat_map
+    (GD/models/GroundingDINO/groundingdino.py module tree; models/GroundingDINO_SwinT_OGC.py)."""
+    s: Dict[str, Tuple[int, ...]] = {}
+    C0, ws, D, Fd = cfg.embed_dim, cfg.window_size, cfg.hidden_dim, cfg.dim_feedforward
+    bb = "backbone.0."
+    s.update({bb + "patch_embed.proj.weight": (C0, 3, 4, 4), bb + "patch_embed.proj.bias": (C0,),
+              bb + "patch_embed.norm.weight": (C0,), bb + "patch_embed.norm.bias": (C0,)})
+    for i, (dep, nh) in enumerate(zip(cfg.depths, cfg.num_heads)):
+        C = C0 * 2 ** i
+        for b in range(dep):
+            p = f"{bb}layers.{i}.blocks.{b}."
+            s.update({p + "norm1.weight": (C,), p + "norm1.bias": (C,),
+                      p + "attn.relative_position_bias_table": ((2 * ws - 1) ** 2, nh),
+                      p + "attn.qkv.weight": (3 * C, C), p + "attn.qkv.bias": (3 * C,),
+                      p + "attn.proj.weight": (C, C), p + "attn.proj.bias": (C,),
+                      p + "norm2.weight": (C,), p + "norm2.bias": (C,),
+                      p + "mlp.fc1.weight": (4 * C, C), p + "mlp.fc1.bias": (4 * C,),
+                      p + "mlp.fc2.weight": (C, 4 * C), p + "mlp.fc2.bias": (C,)})
+        if i < len(cfg.depths) - 1:
+            p = f"{bb}layers.{i}.downsample."
+            s.update({p + "reduction.weight": (2 * C, 4 * C), p + "norm.weight": (4 * C,), p + "norm.bias": (4 * C,)})
+        if i in cfg.out_indices:
+            s.update({f"{bb}norm{i}.weight": (C,), f"{bb}norm{i}.bias": (C,)})
+    chans = [C0 * 2 ** i for i in cfg.out_indices]
+    for l in range(cfg.num_feature_levels):
+        s[f"input_proj.{l}.0.weight"] = (D, chans[l], 1, 1) if l < len(chans) else (D, chans[-1], 3, 3)
+        s.update({f"input_proj.{l}.0.bias": (D,), f"input_proj.{l}.1.weight": (D,), f"input_proj.{l}.1.bias": (D,)})
+    t = "transformer."
+    s[t + "level_embed"] = (cfg.num_feature_levels, D)
+    M, L, P = cfg.nheads, cfg.num_feature_levels, cfg.n_points
+    E = Fd // 2
+
+    def lin(p, o, i):
+        s[p + ".weight"], s[p + ".bias"] = (o, i), (o,)
+
+    def ln(p, n=D):
+        s[p + ".weight"], s[p + ".bias"] = (n,), (n,)
+
+    def msda(p):
+        lin(p + "sampling_offsets", M * L * P * 2, D); lin(p + "attention_weights", M * L * P, D)
+        lin(p + "value_proj", D, D); lin(p + "output_proj", D, D)
+
+    def mha(p):
+        s[p + "in_proj_weight"], s[p + "in_proj_bias"] = (3 * D, D), (3 * D,)
+        lin(p + "out_proj", D, D)
+
+    for i in range(cfg.enc_layers):
+        p = f"{t}encoder.layers.{i}."
+        msda(p + "self_attn."); ln(p + "norm1"); lin(p + "linear1", Fd, D); lin(p + "linear2", D, Fd); ln(p + "norm2")
+        p = f"{t}encoder.text_layers.{i}."
+        mha(p + "self_attn."); lin(p + "linear1", Fd // 2, D); lin(p + "linear2", D, Fd // 2); ln(p + "norm1"); ln(p + "norm2")
+        p = f"{t}encoder.fusion_layers.{i}."
+        ln(p + "layer_norm_v"); ln(p + "layer_norm_l")
+        for n in ("v_proj", "l_proj", "values_v_proj", "values_l_proj"):
+            lin(p + "attn." + n, E, D)
+        lin(p + "attn.out_v_proj", D, E); lin(p + "attn.out_l_proj", D, E)
+        s[p + "gamma_v"], s[p + "gamma_l"] = (D,), (D,)
+    for i in range(cfg.dec_layers):
+        p = f"{t}decoder.layers.{i}."
+        msda(p + "cross_attn."); ln(p + "norm1"); mha(p + "ca_text."); ln(p + "catext_norm")
+        mha(p + "self_attn."); ln(p + "norm2"); lin(p + "linear1", Fd, D); lin(p + "linear2", D, Fd); ln(p + "norm3")
+    ln(t + "decoder.norm")
+    lin(t + "decoder.ref_point_head.layers.0", D, 2 * D); lin(t + "decoder.ref_point_head.layers.1", D, D)
+    s[t + "tgt_embed.weight"] = (cfg.num_queries, D)
+    lin(t + "enc_output", D, D); ln(t + "enc_output_norm")
+    for j, (o, i_) in enumerate(((D, D), (D, D), (4, D))):
+        lin(f"{t}enc_out_bbox_embed.layers.{j}", o, i_)
+        lin(f"bbox_embed.0.layers.{j}", o, i_)
+    return s
+
+
+def random_gdino_state_dict(cfg, device, seed: int = 1) -> Dict[str, torch.Tensor]:
+    sd = _fill(gdino_param_shapes(cfg), device, seed)
+    for k in sd:                                   # in_proj_weight has no ".weight" leaf
+        if k.endswith("in_proj_weight"):
+            sd[k] = sd[k] / math.sqrt(sd[k].shape[1]) / 0.5
+        elif k.endswith("in_proj_bias"):
+            sd[k] = 0.2 * sd[k]
+        elif k.endswith("gamma_v") or k.endswith("gamma_l"):
+            sd[k] = 0.2 + 0.1 * sd[k]
+    return sd
+
+
+def random_text_features(cfg, device, n_tokens: int = 4, seed: int = 2) -> torch.Tensor:
+    """Stand-in for feat_map(BERT("object.")) [n_tokens, 256] (no bert-base-uncased offline)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    return 0.5 * torch.randn((n_tokens, cfg.hidden_dim), generator=g, device=device)

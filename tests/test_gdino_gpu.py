@@ -1,0 +1,183 @@
+"""HIP GroundingDINO path vs the CPU oracle (oracle/gdino_ref.py, pinned to the reference by
+tests/golden/gdino_small.npz).  GPU box only."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden" / "gdino_small.npz"
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-30)).item(), ((a - b).norm() / b.norm()).item()
+
+
+def test_ms_deform_attn_forward_reference_abi(dev):
+    """The reference's own op signature (vision.cpp:53-56) against the golden produced by the
+    reference's CPU form, and against the oracle at decoder-like shapes with out-of-range samples."""
+    from inklayer_amd import ops
+    from oracle import gdino_ref
+    g = np.load(GOLD)
+    shapes = [tuple(int(v) for v in s) for s in g["msda_shapes"]]
+    starts = np.cumsum([0] + [a * b for a, b in shapes])[:-1]
+    out = ops.ms_deform_attn_forward(torch.from_numpy(g["msda_value"]).to(dev), torch.tensor(shapes),
+                                     torch.tensor(starts), torch.from_numpy(g["msda_loc"]).to(dev),
+                                     torch.from_numpy(g["msda_w"]).to(dev), 64)
+    assert (out.cpu() - torch.from_numpy(g["msda_out"])).abs().max().item() < 2e-5
+    rs = np.random.RandomState(0)
+    shapes = [(100, 100), (50, 50), (25, 25), (13, 13)]
+    S = sum(a * b for a, b in shapes)
+    v = torch.from_numpy(rs.standard_normal((2, S, 8, 32)).astype(np.float32))
+    loc = torch.from_numpy(rs.uniform(-0.1, 1.1, size=(2, 300, 8, 4, 4, 2)).astype(np.float32))
+    # exact corner / border cases: 0, 1, pixel centres
+    loc[0, 0] = 0.0
+    loc[0, 1] = 1.0
+    loc[0, 2] = 0.5
+    aw = torch.from_numpy(rs.uniform(0, 1, size=(2, 300, 8, 4, 4)).astype(np.float32))
+    ref = gdino_ref.msda_core(v, shapes, loc, aw)
+    starts = np.cumsum([0] + [a * b for a, b in shapes])[:-1]
+    out = ops.ms_deform_attn_forward(v.to(dev), torch.tensor(shapes), torch.tensor(starts), loc.to(dev), aw.to(dev))
+    assert (out.cpu() - ref).abs().max().item() < 3e-5
+    with pytest.raises(Exception):   # B % min(B, im2col_step) != 0 is rejected like the reference (.cu:53)
+        ops.ms_deform_attn_forward(torch.zeros(3, S, 8, 32, device=dev), torch.tensor(shapes), torch.tensor(starts),
+                                   torch.zeros(3, 1, 8, 4, 4, 2, device=dev), torch.zeros(3, 1, 8, 4, 4, device=dev), 2)
+
+
+def test_topk_rowmax(dev):
+    from inklayer_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 13294, 4, generator=g)
+    x[0, 100:140] = 0.25            # a block of exact ties -> must come out in index order
+    x[1, 5] = float("inf")
+    idx, val = ops.topk_rowmax(x.to(dev), 900, want_values=True)
+    key = x.max(-1)[0]
+    ref = torch.sort(key, dim=1, descending=True, stable=True)
+    assert torch.equal(idx.cpu().long(), ref[1][:, :900])
+    assert torch.equal(val.cpu(), ref[0][:, :900])
+
+
+def test_fusion_fewkeys_groupnorm_ops(dev):
+    from inklayer_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, S, T, E = 2, 1129, 4, 1024
+    qv = torch.randn(B * S, 2 * E, generator=g).half()
+    kl = torch.randn(B * T, 2 * E, generator=g).half()
+    ov, ol = ops.biattn_fusion(qv.to(dev), kl.to(dev), B, S, T, 256 ** -0.5)
+    q = qv[:, :E].double().view(B, S, 4, 256).transpose(1, 2)
+    vv = qv[:, E:].double().view(B, S, 4, 256).transpose(1, 2)
+    k = kl[:, :E].double().view(B, T, 4, 256).transpose(1, 2)
+    vl = kl[:, E:].double().view(B, T, 4, 256).transpose(1, 2)
+    aw = (q @ k.transpose(-1, -2)) * 256 ** -0.5
+    rv = (aw.softmax(-1) @ vl).transpose(1, 2).reshape(B * S, E)
+    rl = (aw.transpose(-1, -2).softmax(-1) @ vv).transpose(1, 2).reshape(B * T, E)
+    assert (ov.double().cpu() - rv).abs().max().item() < 3e-3
+    assert (ol.double().cpu() - rl).abs().max().item() < 3e-3
+    # few-key attention with a block mask
+    nq, nk, H, hd = 900, 4, 8, 32
+    q = torch.randn(B * nq, H * hd, generator=g).half()
+    k = torch.randn(B * nk, H * hd, generator=g).half()
+    v = torch.randn(B * nk, H * hd, generator=g).half()
+    o = ops.attn_fewkeys(q.to(dev), k.to(dev), v.to(dev), B=B, n_heads=H, head_dim=hd, scale=hd ** -0.5)
+    qd, kd, vd = (t.double().view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+    r = ((qd @ kd.transpose(-1, -2)) * hd ** -0.5).softmax(-1) @ vd
+    assert (o.double().cpu() - r.transpose(1, 2).reshape(B * nq, H * hd)).abs().max().item() < 2e-3
+    blocked = torch.tensor([[0, 1, 1, 1], [1, 0, 0, 1], [1, 0, 0, 1], [1, 1, 1, 0]], dtype=torch.uint8)
+    q4 = torch.randn(B * 4, 256, generator=g).half()
+    o = ops.attn_fewkeys(q4.to(dev), q4.to(dev), q4.to(dev), B=B, n_heads=4, head_dim=64, scale=0.125,
+                         blocked=blocked.to(dev))
+    qd = q4.double().view(B, 4, 4, 64).transpose(1, 2)
+    a = (qd @ qd.transpose(-1, -2)) * 0.125
+    a = a.masked_fill(blocked.bool()[None, None], float("-inf")).softmax(-1) @ qd
+    assert (o.double().cpu() - a.transpose(1, 2).reshape(B * 4, 256)).abs().max().item() < 2e-3
+    # GroupNorm(32, 256) on NHWC tokens, written at a batch stride
+    x = torch.randn(B * 300, 256, generator=g) * 2 + 0.3
+    gm, bt = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    out = torch.zeros(B * 500, 256, device=dev)
+    ops.groupnorm_nhwc(x.to(dev), B, 300, 32, gm.to(dev), bt.to(dev), 1e-5, out[100:], 500 * 256)
+    r = torch.nn.functional.group_norm(x.view(B, 300, 256).transpose(1, 2).double(), 32, gm.double(), bt.double(), 1e-5)
+    got = out.view(B, 500, 256)[:, 100:400].cpu().double()
+    assert (got - r.transpose(1, 2)).abs().max().item() < 1e-4
+
+
+@pytest.fixture(scope="module")
+def small_dino(dev):
+    from oracle import gdino_ref, sam_ref
+    from inklayer_amd import gdino
+    oc = gdino_ref.GDinoConfig(enc_layers=2, dec_layers=2, num_queries=300)
+    ec = gdino.GDinoConfig(enc_layers=2, dec_layers=2, num_queries=300)
+    sd = sam_ref.seeded_state_dict(gdino_ref.gdino_param_shapes(oc), 77)
+    for k in sd:
+        if k.endswith("gamma_v") or k.endswith("gamma_l"):
+            sd[k] = 0.3 * torch.ones_like(sd[k]) + 0.05 * sd[k]
+    rs = np.random.RandomState(3)
+    text = torch.from_numpy((0.5 * rs.standard_normal((4, 256))).astype(np.float32))
+    eng = gdino.GDinoEngine(sd, ec, dev, encoded_text=text)
+    return sd, oc, eng, text
+
+
+@torch.no_grad()
+def test_detector_stages_match_oracle(dev, small_dino):
+    from oracle import gdino_ref
+    from inklayer_amd import gdino
+    sd, oc, eng, text = small_dino
+    rs = np.random.RandomState(4)
+    img = rs.randint(0, 256, size=(300, 412, 3)).astype(np.uint8)     # odd stage sizes: pads + odd merges
+    mean, std = torch.tensor(oc.__class__.__dict__.get("x", [0.485, 0.456, 0.406])), torch.tensor([0.229, 0.224, 0.225])
+    x = ((torch.from_numpy(img).permute(2, 0, 1).float() / 255.0) - mean.view(3, 1, 1)) / std.view(3, 1, 1)
+    sm, pid = gdino_ref.text_masks_and_position_ids(list(gdino.DEFAULT_TOKEN_IDS))
+    st = {}
+    ref_logits, ref_boxes = gdino_ref.detector_forward(sd, oc, x[None], text, sm, pid, stages=st)
+    est = {"force_topk": st["topk"]}
+    logits, boxes = eng.forward([torch.from_numpy(img).to(dev)], stages=est)
+    for i, f in zip((1, 2, 3), st["feats"]):
+        ref = f[0].permute(1, 2, 0).reshape(-1, f.shape[1])
+        mx, l2 = _rel(est["feats"][i][0], ref)
+        print(f"swin stage {i}: max-rel {mx:.2e} l2-rel {l2:.2e}")
+        assert mx < 2e-2 and l2 < 4e-3
+    mx, l2 = _rel(est["src"], st["src"][0])
+    print(f"input_proj src: max-rel {mx:.2e} l2-rel {l2:.2e}")
+    assert mx < 2e-2 and l2 < 4e-3
+    mx, l2 = _rel(est["memory"], st["memory"][0])
+    print(f"encoder memory: max-rel {mx:.2e} l2-rel {l2:.2e}")
+    assert mx < 3e-2 and l2 < 5e-3
+    mx, l2 = _rel(est["memory_text"], st["memory_text"][0])
+    print(f"memory_text: max-rel {mx:.2e} l2-rel {l2:.2e}")
+    assert mx < 2e-2 and l2 < 5e-3
+    # query selection: the unforced top-k agrees except where logits are within f16 noise of each other
+    key = st["topk_logits"][0]
+    mine = ops_topk = est["topk_logits"].max(-1)[0][0].cpu()
+    print("topk logits max-rel", _rel(mine, key)[0])
+    got = set(torch.sort(mine, descending=True, stable=True)[1][:300].tolist())
+    want = set(st["topk"][0].tolist())
+    print("topk set overlap", len(got & want) / 300)
+    assert len(got & want) >= 0.97 * 300
+    mx, l2 = _rel(est["ref0"], st["refs"][0][0])
+    assert mx < 1e-2
+    # decoder outputs per query: tight on the 90th percentile (a few random-weight queries are
+    # ill-conditioned even between two fp32 runs, see tests/test_oracle_gdino.py)
+    d = (boxes[0].cpu() - ref_boxes[0]).abs().max(-1)[0]
+    print("box err p50/p90/max", d.median().item(), d.quantile(0.9).item(), d.max().item())
+    assert d.quantile(0.9).item() < 5e-3
+    dl = (logits[0].cpu() - ref_logits[0]).abs().max(-1)[0] / ref_logits.abs().max()
+    print("logit err p50/p90/max", dl.median().item(), dl.quantile(0.9).item(), dl.max().item())
+    assert dl.quantile(0.9).item() < 1e-2
+
+
+@torch.no_grad()
+def test_detector_batch2_and_detect_api(dev, small_dino):
+    sd, oc, eng, text = small_dino
+    rs = np.random.RandomState(5)
+    a = torch.from_numpy(rs.randint(0, 256, size=(224, 224, 3)).astype(np.uint8)).to(dev)
+    b = torch.from_numpy(rs.randint(0, 256, size=(224, 224, 3)).astype(np.uint8)).to(dev)
+    l2_, b2_ = eng.forward([a, b])
+    la, ba = eng.forward([a])
+    lb, bb = eng.forward([b])
+    assert (b2_[0] - ba[0]).abs().max().item() < 1e-5 and (b2_[1] - bb[0]).abs().max().item() < 1e-5
+    assert (l2_[1] - lb[0]).abs().max().item() < 1e-4
+    res = eng.detect([a, b], top_n=16)
+    assert len(res) == 2 and res[0][0].shape == (16, 4) and res[0][1].shape == (16,)
+    res = eng.detect([a])
+    assert res[0][0].shape[1] == 4 and (res[0][1] > 0.2).all()
