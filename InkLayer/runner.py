@@ -1,0 +1,89 @@
+"""Pipeline orchestration (reference: InkLayer/runner.py:21-103): same signature, same output tree
+for the detector -> segmentor part:  <out_base_dir>/<name>/{input.png, bboxes.json, masks/mask_i.png,
+segmented_sketch.png, bboxes.png}.  Refinement and inpainting are outside this build's scope
+(SURVEY §2 rows 7-8): if the reference's refinement package is importable it is called exactly like
+the reference does, otherwise the step is skipped with a message."""
+import os
+import shutil
+
+from PIL import Image, ImageDraw
+
+from InkLayer.detector.gdino import run_ft_dino_on_sketch
+from InkLayer.segmentor.sam import run_SAM
+from InkLayer.utils.processing import process_dino_output, save_norm_bboxes
+
+
+def _draw_boxes(input_pil, boxes):
+    im = input_pil.copy()
+    d = ImageDraw.Draw(im)
+    for b in boxes:
+        d.rectangle([b[0], b[1], b[2], b[3]], outline=(220, 40, 40), width=2)
+    return im
+
+
+def _colour_by_masks(input_pil, masks_pils):
+    import numpy as np
+    base = np.asarray(input_pil).astype("float32")
+    out = base.copy()
+    for i, m in enumerate(masks_pils):
+        hue = (i * 0.61803398875) % 1.0
+        col = 255.0 * np.array([0.6 + 0.4 * abs(((hue * 6 + k) % 6) / 3 - 1) for k in (0, 4, 2)], dtype="float32")
+        sel = np.asarray(m, dtype=bool)
+        out[sel] = 0.5 * base[sel] + 0.5 * col
+    return Image.fromarray(out.clip(0, 255).astype("uint8"))
+
+
+def run_inklayer_pipeline(input_path, out_base_dir, no_intermediate=False, inpaint=False):
+    input_name = os.path.basename(input_path).split(".")[0]
+    input_pil = Image.open(input_path).convert("RGB")
+    out_dir = os.path.join(out_base_dir, input_name)
+    if os.path.exists(out_dir) and len(os.listdir(out_dir)) > 0:
+        shutil.rmtree(out_dir)                                   # reference: `rm -r`
+    os.makedirs(out_dir, exist_ok=True)
+    input_pil.save(os.path.join(out_dir, "input.png"))
+
+    # detector -> boxes (runner.py:34-44): JSON gets the int()-truncated pixel boxes, SAM the float ones
+    dino_out = run_ft_dino_on_sketch(sketch_path=input_path)
+    boxes_tensor, phrases = process_dino_output(dino_out, input_pil)
+    boxes_int = [[int(v) for v in box] for box in boxes_tensor.tolist()]
+    save_norm_bboxes(bboxes_list=boxes_int, scores_list=dino_out["scores"], input_pil=input_pil,
+                     out_path=os.path.join(out_dir, "bboxes.json"))
+
+    # segmentor -> masks (runner.py:49-64)
+    input_pil = Image.open(input_path).convert("RGB")
+    masks_np = run_SAM(image_pil=input_pil, boxes_filt=boxes_tensor)
+    masks_pils = [Image.fromarray(m) for m in masks_np]
+    masks_dir = os.path.join(out_dir, "masks")
+    os.makedirs(masks_dir, exist_ok=True)
+    for i, m in enumerate(masks_pils):
+        m.save(os.path.join(masks_dir, f"mask_{i}.png"))         # PIL mode "1"
+    _colour_by_masks(input_pil, masks_pils).save(os.path.join(out_dir, "segmented_sketch.png"))
+    _draw_boxes(input_pil, boxes_int).save(os.path.join(out_dir, "bboxes.png"))
+    input_pil.save(os.path.join(out_dir, "input.png"))
+
+    try:                                                         # runner.py:69-73 (out of scope here)
+        from InkLayer.refinement.mask_cleaner import run_clean_masks_on_sketch_dir
+        from InkLayer.refinement.bbox_filter import run_postprocess_boxes_on_sketch_dir
+        from InkLayer.refinement.refiner import run_refinement_on_sketch_dir
+    except ImportError:
+        print("InkLayer.refinement is not part of this build: skipping mask cleanup / NMS / refinement.")
+    else:
+        run_clean_masks_on_sketch_dir(out_dir)
+        run_refinement_on_sketch_dir(out_dir, run_postprocess_boxes_on_sketch_dir(out_dir, sketch_iou_thresh=0.2))
+    if inpaint:
+        print("Inpainting (diffusers) is not part of this build: skipped.")
+    else:
+        print("Skipping inpainting step as 'inpaint' is set to False.")
+    if no_intermediate:
+        keep = {"masks_final", "complete_layers", "complete_layers_rgba", "bboxes_final.json",
+                "bboxes_final.png", "segmented_sketch_final.png", "depth_map.png", "input.png"}
+        for item in os.listdir(out_dir):
+            if item in keep:
+                continue
+            path = os.path.join(out_dir, item)
+            shutil.rmtree(path) if os.path.isdir(path) else os.remove(path)
+    return out_dir
+
+
+def run_inpaint_single_layer(request_data, cur_dir, out_dir):
+    raise NotImplementedError("layer inpainting (InkLayer/inpainting, diffusers) is outside this build's scope")

@@ -1,0 +1,98 @@
+"""Image-parallel multi-GPU support: one process per GPU, ONE collective (weight broadcast).
+
+The path shards by independent units (sketches): rank r takes images i with i % world == r
+(SURVEY §8e).  The only exchange is at start-up: rank 0 owns the checkpoint (or the seeded random
+weights) and broadcasts them as a few large flat buffers over RCCL/xGMI (torch.distributed backend
+"nccl" == RCCL on ROCm; "gloo" in the CPU tests).  No per-batch collectives.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+BUCKET_BYTES = 1 << 30   # 1 GiB flat buckets: few, large messages (xGMI links are per-peer bound)
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_process_group(backend: str | None = None) -> Tuple[int, int, int]:
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Static round-robin: item i -> rank i % world."""
+    return list(range(rank, n_items, world))
+
+
+def broadcast_state_dict(spec: Dict[str, Tuple[Tuple[int, ...], torch.dtype]],
+                         sd: Dict[str, torch.Tensor] | None, device, src: int = 0) -> Dict[str, torch.Tensor]:
+    """Every rank knows `spec` (name -> (shape, dtype)); only `src` needs `sd`.  Tensors travel packed into
+    <= BUCKET_BYTES flat buffers per dtype, one dist.broadcast each; receivers get views into the buffers."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        assert sd is not None
+        return {k: sd[k].to(device) for k in spec}
+    out: Dict[str, torch.Tensor] = {}
+    by_dtype: Dict[torch.dtype, List[str]] = {}
+    for name, (_, dt) in spec.items():
+        by_dtype.setdefault(dt, []).append(name)
+    for dt, names in by_dtype.items():
+        esz = torch.empty((), dtype=dt).element_size()
+        bucket: List[str] = []
+        nbytes = 0
+
+        def flush():
+            nonlocal bucket, nbytes
+            if not bucket:
+                return
+            numels = [int(torch.Size(spec[n][0]).numel()) for n in bucket]
+            flat = torch.empty(sum(numels), dtype=dt, device=device)
+            if rank == src:
+                off = 0
+                for n, ne in zip(bucket, numels):
+                    flat[off:off + ne].copy_(sd[n].reshape(-1))
+                    off += ne
+            dist.broadcast(flat, src=src)
+            off = 0
+            for n, ne in zip(bucket, numels):
+                out[n] = flat[off:off + ne].view(spec[n][0])
+                off += ne
+            bucket, nbytes = [], 0
+
+        for n in names:
+            sz = int(torch.Size(spec[n][0]).numel()) * esz
+            if nbytes + sz > BUCKET_BYTES and bucket:
+                flush()
+            bucket.append(n)
+            nbytes += sz
+        flush()
+    return out
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier() -> None:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

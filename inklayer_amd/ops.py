@@ -17,6 +17,16 @@ ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2}
 F16, F32 = torch.float16, torch.float32
 
 
+_GEMM_TRACE = None
+
+
+def set_gemm_trace(lst) -> None:
+    """bench.py instrumentation: when `lst` is a list, every gemm() launch is bracketed by two HIP events
+    on the launch stream and (flops, start, end) is appended; None switches it off."""
+    global _GEMM_TRACE
+    _GEMM_TRACE = lst
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -64,7 +74,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     p.act = ACT[act]
     p.c_f16 = 1 if out.dtype == F16 else 0
     assert out.dtype in (F16, F32)
-    check(_lib.lib().ink_gemm_f16(C.byref(p), _stream()), "ink_gemm_f16")
+    if _GEMM_TRACE is None:
+        check(_lib.lib().ink_gemm_f16(C.byref(p), _stream()), "ink_gemm_f16")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.lib().ink_gemm_f16(C.byref(p), _stream()), "ink_gemm_f16")
+        e1.record()
+        _GEMM_TRACE.append((2.0 * M * N * K, e0, e1))
     return out
 
 

@@ -1,0 +1,83 @@
+"""Batched detector -> segmentor pipeline on one MI355X (the unit that is sharded image-parallel).
+
+One call = B sketches: GroundingDINO proposes boxes for all B images in one batched forward, the
+boxes cross to the host once (900 x 8 floats per image) for the threshold + box glue that the
+reference also does on the CPU (GD/util/inference.py:70-75, InkLayer/utils/processing.py:6-28), SAM
+encodes all B images in one batched forward and decodes each image's boxes.  Both engines stay
+resident in HBM (the reference reloads SAM's 2.4 GB checkpoint per image, InkLayer/segmentor/sam.py:23).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import gdino as gd
+from . import sam as sm
+
+
+@dataclass
+class SketchResult:
+    boxes_xyxy_norm: np.ndarray       # [n,4] float64, normalised (the detector plugin's "bboxes")
+    scores: np.ndarray                # [n]
+    boxes_pixel: torch.Tensor         # [n,4] float32 pixel xyxy (what SAM is prompted with)
+    masks: torch.Tensor               # [n,H,W] uint8 on the GPU (0/1)
+
+
+def boxes_to_pixels(norm_xyxy: np.ndarray, W: int, H: int) -> torch.Tensor:
+    """process_boxes_ours (InkLayer/utils/processing.py:6-28), vectorised with the same f32 steps."""
+    if len(norm_xyxy) == 0:
+        return torch.zeros((0, 4), dtype=torch.float32)
+    x1, y1, x2, y2 = (norm_xyxy[:, i] for i in range(4))
+    w, h = x2 - x1, y2 - y1
+    b = torch.tensor(np.stack([x1 + w / 2, y1 + h / 2, w, h], -1)).float()
+    b = b * torch.tensor([W, H, W, H], dtype=torch.float32)
+    b[:, :2] -= b[:, 2:] / 2
+    b[:, 2:] += b[:, :2]
+    return b
+
+
+class InkLayerPipeline:
+    def __init__(self, detector: gd.GDinoEngine, segmentor: sm.SamEngine):
+        self.det, self.seg = detector, segmentor
+        self.dev = detector.dev
+
+    def prepare(self, images_rgb: Sequence[np.ndarray]):
+        """Host side: the two PIL resizes of the reference (800 shorter side for the detector,
+        1024 longest side for SAM incl. its channel quirk), then ONE upload each."""
+        det_in, sam_in, sizes = [], [], []
+        L = self.seg.cfg.img_size
+        for im in images_rgb:
+            det_in.append(torch.from_numpy(gd.resize_for_detector(im)).to(self.dev, non_blocking=True))
+            rs = sm.resize_longest_side(np.ascontiguousarray(im[..., ::-1]), L)   # sam.py:24-26 channel reversal
+            sam_in.append(torch.from_numpy(np.ascontiguousarray(rs)).to(self.dev, non_blocking=True))
+            sizes.append(((im.shape[0], im.shape[1]), tuple(rs.shape[:2])))
+        return det_in, sam_in, sizes
+
+    @torch.no_grad()
+    def run_prepared(self, det_in, sam_in, sizes, top_n: Optional[int] = None) -> List[SketchResult]:
+        dets = self.det.detect(det_in, top_n=top_n)
+        emb = self.seg.encode(sam_in)
+        L = self.seg.cfg.img_size
+        out = []
+        for b, ((boxes_cxcywh, scores), ((oh, ow), (ih, iw))) in enumerate(zip(dets, sizes)):
+            bx = boxes_cxcywh.double().numpy().reshape(-1, 4)
+            xyxy = np.stack([bx[:, 0] - bx[:, 2] / 2, bx[:, 1] - bx[:, 3] / 2, bx[:, 0] + bx[:, 2] / 2,
+                             bx[:, 1] + bx[:, 3] / 2], -1)
+            pix = boxes_to_pixels(xyxy, ow, oh)
+            if len(pix) == 0:
+                masks = torch.zeros((0, oh, ow), dtype=torch.uint8, device=self.dev)
+            else:
+                # ResizeLongestSide.apply_boxes_torch (SA/utils/transforms.py:67-91)
+                nh, nw = sm.preprocess_shape(oh, ow, L)
+                tb = pix.reshape(-1, 2, 2).clone()
+                tb[..., 0] = tb[..., 0] * (nw / ow)
+                tb[..., 1] = tb[..., 1] * (nh / oh)
+                masks = self.seg.decode(emb[b], tb.reshape(-1, 4), (ih, iw), (oh, ow))
+            out.append(SketchResult(xyxy, scores.numpy(), pix, masks))
+        return out
+
+    def run_batch(self, images_rgb: Sequence[np.ndarray], top_n: Optional[int] = None) -> List[SketchResult]:
+        return self.run_prepared(*self.prepare(images_rgb), top_n=top_n)
