@@ -238,7 +238,7 @@ class GDinoEngine:
 
         # ---- Swin-T
         bb = "backbone.0."
-        pw = sd[bb + "patch_embed.proj.weight"].detach().to(torch.float32).reshape(cfg.embed_dim, 48)
+        pw = sd[bb + "patch_embed.proj.weight"].detach().to(torch.float32).cpu().reshape(cfg.embed_dim, 48)
         w["pe.w"] = torch.cat([pw, torch.zeros(cfg.embed_dim, 16)], 1).to(dev, F16).contiguous()
         w["pe.b"] = f(bb + "patch_embed.proj.bias")
         ln("pe.norm", bb + "patch_embed.norm")
@@ -259,7 +259,7 @@ class GDinoEngine:
                 lin(d + ".proj", p + "attn.proj")
                 lin(d + ".fc1", p + "mlp.fc1")
                 lin(d + ".fc2", p + "mlp.fc2")
-                tab = sd[p + "attn.relative_position_bias_table"].detach().to(torch.float32)
+                tab = sd[p + "attn.relative_position_bias_table"].detach().to(torch.float32).cpu()
                 bias = torch.zeros((nh, ws * ws, 64))
                 bias[:, :, :ws * ws] = tab[rel_index].view(ws * ws, ws * ws, nh).permute(2, 0, 1) / scale
                 w[d + ".bias"] = bias.to(dev).contiguous()
