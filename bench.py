@@ -58,6 +58,11 @@ def cpu_baseline(n_boxes):
     from oracle import gdino_ref, sam_ref
     from inklayer_amd import synthetic, weights_init, sam as psam, gdino as pgd
     torch.manual_seed(0)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, ncpu))       # the threads this process may actually run on
     scfg, gcfg = sam_ref.SamConfig(), gdino_ref.GDinoConfig()
     ssd = weights_init.random_sam_state_dict(psam.SamConfig(), "cpu", 0)
     gsd = weights_init.random_gdino_state_dict(pgd.GDinoConfig(), "cpu", 1)
