@@ -126,8 +126,8 @@ def main():
     assert len(res) == B and res[0].masks.shape == (args.boxes, 1024, 1024)
 
     if rank == 0:
-        gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in trace)
-        gemm_flops = sum(f for f, _, _ in trace)
+        gemm_ms = sum(t[1].elapsed_time(t[2]) for t in trace)
+        gemm_flops = sum(t[0] for t in trace)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         sketches = B * world * args.steps
         out = {

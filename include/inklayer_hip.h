@@ -59,6 +59,10 @@ typedef struct InkGemm {
 #define INK_ACT_GELU 1
 #define INK_ACT_RELU 2
 int ink_gemm_f16(const InkGemm* p, void* stream);
+/* Tuning knob (tools/gemm_sweep.py): force tile variant v >= 0 for every following ink_gemm_f16 call;
+ * -1 restores the built-in shape heuristic.  Results are identical across variants up to f32
+ * summation order. */
+int ink_gemm_set_variant(int32_t v);
 
 /* ------------------------------------------------------------------------
  * Row LayerNorm with optional row gather (fuses window-partition / pad /
@@ -232,6 +236,14 @@ int ink_biattn_fusion(const void* QV_f16, const void* KL_f16, int32_t B, int32_t
 int ink_attn_fewkeys(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                      int32_t B, int32_t n_q, int32_t n_k, int32_t n_heads, int32_t head_dim, float scale,
                      const uint8_t* blocked, void* O, int64_t ldo, void* stream);
+
+/* softmax(scale q k^T) v for n_q <= 8 queries per batch entry against MANY keys (SAM decoder tokens ->
+ * image: 7 x 4096, SA/modeling/transformer.py:163-168): f16 rows, head h at columns [h*hd,(h+1)*hd),
+ * hd in {16,32}; q_batch_rows / kv_batch_rows as in InkAttn; O dense f16 [n_batch*n_q, ..]. */
+int ink_attn_fewq(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                  int32_t n_batch, int32_t n_q, int32_t n_k, int32_t n_heads, int32_t head_dim, float scale,
+                  const int32_t* q_batch_rows, const int32_t* kv_batch_rows, void* O, int64_t ldo,
+                  void* stream);
 
 /* Two-stage query selection (transformer.py:293-300): indices of the K largest max_t logits[b,s,t],
  * descending, ties -> lower index.  logits f32 [B,S,T], S <= 16384; out_idx int32 [B,K]. */

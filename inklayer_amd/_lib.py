@@ -41,6 +41,7 @@ class InkAttn(C.Structure):
 SIGNATURES = {
     "ink_abi_version": [],
     "ink_gemm_f16": [C.POINTER(InkGemm), c_void_p],
+    "ink_gemm_set_variant": [c_int],
     "ink_layernorm_rows": [c_void_p, c_i64, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                            c_void_p, c_void_p, c_i64, c_int, c_void_p],
     "ink_add_cvt_f16": [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p],
@@ -68,6 +69,8 @@ SIGNATURES = {
                           c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "ink_attn_fewkeys": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int,
                          c_float, c_void_p, c_void_p, c_i64, c_void_p],
+    "ink_attn_fewq": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int,
+                      c_float, c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
     "ink_topk_rowmax": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ink_sine_embed4": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "ink_box_refine": [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p],

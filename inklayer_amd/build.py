@@ -20,6 +20,8 @@ OBJDIR = LIBDIR / "obj"
 LIB = LIBDIR / "libinklayer_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-mllvm", "-amdgpu-mfma-vgpr-form",   # MFMA C/D in arch VGPRs: no v_accvgpr copies around softmax
+
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 

@@ -35,21 +35,31 @@ __device__ __forceinline__ f16x8 cvt8(const f32x16& s, int base) {
   return r;
 }
 
-template <int HD, int MODE, int NW>
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+template <int HD, int MODE, int NW, bool ALLKV = false>
 __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
   constexpr int NQKB = HD / 16;
   constexpr int NQK = NQKB + (MODE == 2 ? 2 : 0);
   constexpr int NB = (HD + 31) / 32;
   constexpr int DVP = NB * 32;
+  constexpr bool LSUM_MFMA = DVP >= HD + 8;     // room for a ones-column in V's padding -> l = P @ 1 for free
   constexpr int CH = HD / 8;                    // 16-B chunks of real data per K/V row
   constexpr int KROW = ((NQK * 2) | 1) * 16;    // odd chunk count -> conflict-free b128 reads
   constexpr int VROW = DVP * 2;                 // 64 or 192 B: conflict-free tr_b16 reads
   constexpr int NT = NW * 64;
   constexpr int KIT = (64 * CH + NT - 1) / NT;
   constexpr float NEG = -1e30f;
-  __shared__ __attribute__((aligned(16))) char smem[64 * KROW + 64 * VROW];
+  constexpr int TILEB = 64 * KROW + 64 * VROW;   // LDS bytes of one 64-key K/V tile
+  constexpr int MAXT = ALLKV ? 4 : 1;             // ALLKV: every tile (n_k <= 256) resident at once
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = smem + 64 * KROW;
+  char* sR = smem + MAXT * TILEB;                 // MODE 1: rel_w rows, [8 float4][NT lanes]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, hh = lane >> 5;
@@ -71,10 +81,9 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
     qf[NQKB] = *(const f16x8*)(R + 8 * hh);
     qf[NQKB + 1] = *(const f16x8*)(R + 16 + 8 * hh);
   }
-  float relw[2][16];   // mode 1: rel_w of this query; mode 3: the whole (bias + mask) row
+  float bias3[2][16];   // mode 3 only: the whole (bias + mask) row of this query (single tile)
   const float* RH = nullptr;
   if constexpr (MODE == 3) {
-    // rows padded to 64 floats, pre-divided by scale: bias[h][q][64] + mask[b % n_mask][q][64]
     const float* bp = p.dense_bias + ((int64_t)h * p.n_q + q_c) * 64;
     const float* mp = p.dense_mask ? p.dense_mask + ((int64_t)(b % p.n_mask) * p.n_q + q_c) * 64 : nullptr;
 #pragma unroll
@@ -84,44 +93,59 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
         f32x4 v = *(const f32x4*)(bp + sub * 32 + 8 * g + 4 * hh);
         if (mp) v += *(const f32x4*)(mp + sub * 32 + 8 * g + 4 * hh);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) relw[sub][4 * g + r] = v[r];
+        for (int r = 0; r < 4; ++r) bias3[sub][4 * g + r] = v[r];
       }
   }
   if constexpr (MODE == 1) {
+    // rel_w[q, kw] of this lane's query -> LDS, float4 i of lane t at ((i*NT + t)*16): every tile re-reads it
+    // straight into the S accumulators (LDS pipe, no VALU, no registers held across the loop)
     const float* RW = p.rel_w + ((int64_t)bh * p.n_q + q_c) * 64;
     RH = p.rel_h + ((int64_t)bh * p.n_q + q_c) * 64;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = *(const f32x4*)(RW + sub * 32 + 8 * g + 4 * hh);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) relw[sub][4 * g + r] = v[r];
-      }
+    for (int i = 0; i < 8; ++i)
+      *(f32x4*)(sR + (i * NT + tid) * 16) = *(const f32x4*)(RW + (i >> 2) * 32 + 8 * (i & 3) + 4 * hh);
   }
 
-  // zero the V pad columns once (never overwritten afterwards)
+  // V pad columns: zero, except a ones-column (d = HD for the lower half-wave, HD+4 for the upper) so that the
+  // PV MFMA also yields l = sum_k P[q,k] in o[NB-1][..] of BOTH halves
   if constexpr (DVP > HD) {
     constexpr int PCH = (DVP - HD) / 8;
-    for (int i = tid; i < 64 * PCH; i += NT) {
-      const int row = i / PCH, cc = CH + i % PCH;
-      *(f16x8*)(sV + row * VROW + cc * 16) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < MAXT * 64 * PCH; i += NT) {
+      const int row = (i / PCH) % 64, pc = i % PCH, tl = i / (64 * PCH);
+      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (LSUM_MFMA && pc == 0) { z[0] = (f16)1; z[4] = (f16)1; }
+      *(f16x8*)(sV + tl * TILEB + row * VROW + (CH + pc) * 16) = z;
     }
   }
+  // register index / half that holds row d = HD (+4 for hh = 1) of O^T
+  constexpr int LI = HD / 32, LR = (((HD % 32) / 8) * 4);
 
   const int64_t kvb = p.kv_batch_rows ? (int64_t)p.kv_batch_rows[b] : (int64_t)b * p.n_k;
-  const f16* Kb = (const f16*)p.K + kvb * p.ldk + h * HD;
-  const f16* Vb = (const f16*)p.V + kvb * p.ldv + h * HD;
+  const char* Kb = (const char*)((const f16*)p.K + kvb * p.ldk + h * HD);
+  const char* Vb = (const char*)((const f16*)p.V + kvb * p.ldv + h * HD);
+  // per-thread byte offsets of its K/V chunks inside a 64-key tile (32-bit; the tile base is wave-uniform)
+  int koff_g[KIT], voff_g[KIT], loff_k[KIT], loff_v[KIT];
+#pragma unroll
+  for (int it = 0; it < KIT; ++it) {
+    const int ci = tid + it * NT;
+    const int row = (ci / CH) & 63, cc = ci % CH;
+    koff_g[it] = (row * (int)p.ldk + cc * 8) * 2;
+    voff_g[it] = (row * (int)p.ldv + cc * 8) * 2;
+    loff_k[it] = row * KROW + cc * 16;
+    loff_v[it] = row * VROW + cc * 16;
+  }
   f16x8 kreg[KIT], vreg[KIT];
   auto load_tile = [&](int t) {
+    const char* kt = Kb + (int64_t)t * 64 * p.ldk * 2;
+    const char* vt = Vb + (int64_t)t * 64 * p.ldv * 2;
+    const bool full = (t + 1) * 64 <= p.n_k;
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
       const int ci = tid + it * NT;
-      const int row = ci / CH, cc = ci % CH;
-      const int key = t * 64 + row;
-      if (ci < 64 * CH && key < p.n_k) {
-        kreg[it] = *(const f16x8*)(Kb + (int64_t)key * p.ldk + cc * 8);
-        vreg[it] = *(const f16x8*)(Vb + (int64_t)key * p.ldv + cc * 8);
+      const bool ok = ci < 64 * CH && (full || t * 64 + ci / CH < p.n_k);
+      if (ok) {
+        kreg[it] = *(const f16x8*)(kt + koff_g[it]);
+        vreg[it] = *(const f16x8*)(vt + voff_g[it]);
       } else {
         kreg[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         vreg[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -131,14 +155,12 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
   auto store_tile = [&](int t) {
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
-      const int ci = tid + it * NT;
-      const int row = ci / CH, cc = ci % CH;
-      if (ci < 64 * CH) {
-        *(f16x8*)(sK + row * KROW + cc * 16) = kreg[it];
-        *(f16x8*)(sV + row * VROW + cc * 16) = vreg[it];
+      if (tid + it * NT < 64 * CH) {
+        *(f16x8*)(sK + loff_k[it]) = kreg[it];
+        *(f16x8*)(sV + loff_v[it]) = vreg[it];
       }
     }
-    if constexpr (MODE == 2) {  // one-hot (kh, kw) columns of K'
+    if constexpr (MODE == 2 && !ALLKV) {  // one-hot (kh, kw) columns of K'
       for (int i = tid; i < 256; i += NT) {
         const int row = i >> 2, c4 = i & 3;
         const int key = t * 64 + row;
@@ -168,26 +190,79 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
   const int koff1 = (32 + lq) * KROW + hh * 16;
   const int voff = (4 * hh + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
-  load_tile(0);
-  for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();  // previous tile fully consumed
-    store_tile(t);
+  float rh_next = 0.f;
+  if constexpr (MODE == 1) rh_next = RH[0];
+  if constexpr (ALLKV) {
+    // all K/V rows of this (batch, head) at once: every global load is issued back-to-back, ONE barrier,
+    // then the tile loop runs without any synchronisation (14x14 windows: 196 keys = 4 tiles).
+    constexpr int KALL = (MAXT * 64 * CH + NT - 1) / NT;
+    f16x8 ka[KALL], va[KALL];
+#pragma unroll
+    for (int it = 0; it < KALL; ++it) {
+      const int ci = tid + it * NT;
+      const int key = ci / CH, cc = ci % CH;
+      if (ci < MAXT * 64 * CH && key < p.n_k) {
+        ka[it] = *(const f16x8*)(Kb + ((int64_t)key * p.ldk + cc * 8) * 2);
+        va[it] = *(const f16x8*)(Vb + ((int64_t)key * p.ldv + cc * 8) * 2);
+      } else {
+        ka[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        va[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+    if constexpr (MODE == 2) {
+      for (int i = tid; i < MAXT * 256; i += NT) {
+        const int key = i >> 2, c4 = i & 3;
+        const int kh = key / p.grid_w, kw = key - kh * p.grid_w + p.grid_w;
+        f16x8 e;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int col = c4 * 8 + j;
+          e[j] = (key < p.n_k && (col == kh || col == kw)) ? (f16)1 : (f16)0;
+        }
+        *(f16x8*)(sK + (key >> 6) * TILEB + (key & 63) * KROW + (CH + c4) * 16) = e;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < KALL; ++it) {
+      const int ci = tid + it * NT;
+      const int key = ci / CH, cc = ci % CH;
+      if (ci < MAXT * 64 * CH) {
+        *(f16x8*)(sK + (key >> 6) * TILEB + (key & 63) * KROW + cc * 16) = ka[it];
+        *(f16x8*)(sV + (key >> 6) * TILEB + (key & 63) * VROW + cc * 16) = va[it];
+      }
+    }
     __syncthreads();
-    if (t + 1 < ntiles) load_tile(t + 1);  // in flight during the MFMAs below
+  } else {
+    load_tile(0);
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    if constexpr (!ALLKV) {
+      __syncthreads();  // previous tile fully consumed
+      store_tile(t);
+      __syncthreads();
+      if (t + 1 < ntiles) load_tile(t + 1);  // in flight during the MFMAs below
+    }
+    const char* tK = sK + (ALLKV ? t * TILEB : 0);
+    const char* tV = sV + (ALLKV ? t * TILEB : 0);
+    const float rh = rh_next;               // rel_h[q, kh = t]: a per-tile constant of this lane
+    if constexpr (MODE == 1) {
+      if (t + 1 < ntiles) rh_next = RH[t + 1];   // prefetch: never a dependent load at the top of a tile
+    }
 
     f32x16 s0, s1;
     if constexpr (MODE == 1) {
-      const float rh = RH[t];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s0[r] = relw[0][r] + rh;
-        s1[r] = relw[1][r] + rh;
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 a = *(const f32x4*)(sR + (g * NT + tid) * 16);
+        const f32x4 bq = *(const f32x4*)(sR + ((4 + g) * NT + tid) * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[4 * g + r] = a[r]; s1[4 * g + r] = bq[r]; }
       }
     } else if constexpr (MODE == 3) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s0[r] = relw[0][r];
-        s1[r] = relw[1][r];
+        s0[r] = bias3[0][r];
+        s1[r] = bias3[1][r];
       }
     } else {
 #pragma unroll
@@ -195,8 +270,8 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
     }
 #pragma unroll
     for (int s = 0; s < NQK; ++s) {
-      const f16x8 k0 = *(const f16x8*)(sK + koff0 + s * 32);
-      const f16x8 k1 = *(const f16x8*)(sK + koff1 + s * 32);
+      const f16x8 k0 = *(const f16x8*)(tK + koff0 + s * 32);
+      const f16x8 k1 = *(const f16x8*)(tK + koff1 + s * 32);
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
     }
@@ -208,13 +283,17 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
         if (key + 32 >= p.n_k) s1[r] = NEG;
       }
     }
-    float mx = fmaxf(s0[0], s1[0]);
+    // row max (this half's 32 keys, then the other half); rel_h is added AFTER the max (it is constant)
+    float mx = max3(s0[0], s0[1], s1[0]);
+    mx = max3(mx, s1[1], s0[2]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+    for (int r = 3; r < 16; r += 2) mx = max3(mx, s0[r], s0[r + 1 < 16 ? r + 1 : r]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) mx = max3(mx, s1[r], s1[r + 1]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * c);
+    const float m_new = fmaxf(m_run, (mx + rh) * c);
     if (__any(m_new > m_run)) {
-      const float alpha = exp2f(m_run - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < NB; ++i)
@@ -222,14 +301,23 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
       m_run = m_new;
     }
-    float ps = 0.f;
+    const float koff = rh * c - m_run;      // p = 2^((s + rh) * c - m)
+    if constexpr (LSUM_MFMA) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s0[r] = exp2f(fmaf(s0[r], c, -m_run));
-      s1[r] = exp2f(fmaf(s1[r], c, -m_run));
-      ps += s0[r] + s1[r];
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, koff));
+        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, koff));
+      }
+    } else {
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, koff));
+        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, koff));
+        ps += s0[r] + s1[r];
+      }
+      l_run += ps;
     }
-    l_run += ps;
     f16x8 pf[4];
     pf[0] = cvt8(s0, 0);
     pf[1] = cvt8(s0, 8);
@@ -239,7 +327,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const char* base = sV + voff + (16 * ks) * VROW + i * 64;
+        const char* base = tV + voff + (16 * ks) * VROW + i * 64;
         const f16x4 a0 = tr_read(base);
         const f16x4 a1 = tr_read(base + 8 * VROW);
         const f16x8 vf = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -248,7 +336,12 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
     }
   }
 
-  const float ltot = l_run + __shfl_xor(l_run, 32, 64);
+  float ltot;
+  if constexpr (LSUM_MFMA) {
+    ltot = o[LI][LR];                        // row d = HD (hh = 0) / HD + 4 (hh = 1) of O^T: sum_k P
+  } else {
+    ltot = l_run + __shfl_xor(l_run, 32, 64);
+  }
   const float inv = 1.0f / ltot;
   if (q_ok) {
     f16* Orow = (f16*)p.O + ((int64_t)b * p.n_q + q_idx) * p.ldo + h * HD;  // O is always dense per batch entry
@@ -356,17 +449,24 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
   INK_CHECK_ARG(((uintptr_t)p.O & 7) == 0);
   hipStream_t s = (hipStream_t)stream;
   const int bhn = p.n_batch * p.n_heads;
-#define INK_FA(HD, MODE, NW)                                                              \
-  {                                                                                    \
-    const int nqb = (p.n_q + NW * 32 - 1) / (NW * 32);                                     \
-    hipLaunchKernelGGL((flash_attn_kernel<HD, MODE, NW>), dim3(bhn * nqb), dim3(NW * 64), 0, s, p); \
+#define INK_FA_X(HD, MODE, NW, ALL)                                                                      \
+  {                                                                                                        \
+    constexpr int nqk_ = HD / 16 + (MODE == 2 ? 2 : 0);                                                    \
+    constexpr int lds_ = (ALL ? 4 : 1) * (64 * (((nqk_ * 2) | 1) * 16) + 64 * (((HD + 31) / 32) * 64)) +   \
+                         (MODE == 1 ? NW * 64 * 128 : 0);                                               \
+    static bool attr_ = ((void)hipFuncSetAttribute((const void*)flash_attn_kernel<HD, MODE, NW, ALL>,      \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_), true); \
+    (void)attr_;                                                                                           \
+    const int nqb = (p.n_q + NW * 32 - 1) / (NW * 32);                                                     \
+    hipLaunchKernelGGL((flash_attn_kernel<HD, MODE, NW, ALL>), dim3(bhn * nqb), dim3(NW * 64), lds_, s, p); \
   }
+#define INK_FA(HD, MODE, NW) INK_FA_X(HD, MODE, NW, false)
   if (p.head_dim == 80 && p.bias_mode == 1) {
     INK_CHECK_ARG(p.rel_h && p.rel_w && p.grid_w == 64 && p.n_k % 64 == 0);
     INK_FA(80, 1, 4);
   } else if (p.head_dim == 80 && p.bias_mode == 2) {
-    INK_CHECK_ARG(p.rel_aug && p.grid_w > 0 && p.grid_w <= 16 && p.n_k <= p.grid_w * p.grid_w);
-    INK_FA(80, 2, 7);
+    INK_CHECK_ARG(p.rel_aug && p.grid_w > 0 && p.grid_w <= 16 && p.n_k <= p.grid_w * p.grid_w && p.n_k <= 256);
+    INK_FA_X(80, 2, 7, true);
   } else if (p.head_dim == 80 && p.bias_mode == 0) {
     INK_FA(80, 0, 4);
   } else if (p.head_dim == 32 && p.bias_mode == 0) {
@@ -380,6 +480,7 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
     return INK_ERR_ARG;
   }
 #undef INK_FA
+#undef INK_FA_X
   return ink_launch_status();
 }
 

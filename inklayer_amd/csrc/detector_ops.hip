@@ -351,6 +351,80 @@ __global__ __launch_bounds__(256) void attn_fewkeys_kernel(const f16* __restrict
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Attention of a FEW queries (n_q <= 8) against many keys: SAM decoder token->image attention
+// (7 tokens x 4096 image keys, 8 heads x 16; SA/modeling/transformer.py:163-168, 101-103).
+// One workgroup per (batch, head); thread (qi = tid/32, kl = tid%32) streams keys kl, kl+32, ... with an
+// online softmax, then the 32 key-lanes of each query are merged with half-wave shuffles.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fewq_kernel(const f16* __restrict__ Q, int64_t ldq,
+                                                        const f16* __restrict__ K, int64_t ldk,
+                                                        const f16* __restrict__ V, int64_t ldv, int n_q,
+                                                        int n_k, int n_heads, float scale,
+                                                        const int32_t* __restrict__ q_rows,
+                                                        const int32_t* __restrict__ kv_rows,
+                                                        f16* __restrict__ O, int64_t ldo) {
+  const int b = blockIdx.x / n_heads, h = blockIdx.x % n_heads;
+  const int qi = threadIdx.x >> 5, kl = threadIdx.x & 31;
+  const bool active = qi < n_q;
+  const int64_t q0 = q_rows ? (int64_t)q_rows[b] : (int64_t)b * n_q;
+  const int64_t k0 = kv_rows ? (int64_t)kv_rows[b] : (int64_t)b * n_k;
+  float qv[HD];
+  const f16* qp = Q + (q0 + (active ? qi : 0)) * ldq + h * HD;
+#pragma unroll
+  for (int i = 0; i < HD / 8; ++i) {
+    const f16x8 v = *(const f16x8*)(qp + 8 * i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[8 * i + j] = (float)v[j] * scale;
+  }
+  float m = -3.0e38f, l = 0.f, acc[HD];
+#pragma unroll
+  for (int i = 0; i < HD; ++i) acc[i] = 0.f;
+  for (int key = kl; key < n_k; key += 32) {
+    const f16* kp = K + (k0 + key) * ldk + h * HD;
+    const f16* vp = V + (k0 + key) * ldv + h * HD;
+    float d = 0.f;
+    f16x8 vv[HD / 8];
+#pragma unroll
+    for (int i = 0; i < HD / 8; ++i) {
+      const f16x8 kk = *(const f16x8*)(kp + 8 * i);
+      vv[i] = *(const f16x8*)(vp + 8 * i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d = fmaf(qv[8 * i + j], (float)kk[j], d);
+    }
+    const float mn = fmaxf(m, d);
+    const float a = expf(m - mn), pw = expf(d - mn);
+    l = l * a + pw;
+#pragma unroll
+    for (int i = 0; i < HD / 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[8 * i + j] = fmaf(pw, (float)vv[i][j], acc[8 * i + j] * a);
+    m = mn;
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {       // merge the 32 key-lanes (stays inside one half-wave)
+    const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
+    const float mn = fmaxf(m, mo);
+    const float a = expf(m - mn), bsc = expf(mo - mn);
+    l = l * a + lo * bsc;
+#pragma unroll
+    for (int i = 0; i < HD; ++i) acc[i] = acc[i] * a + __shfl_xor(acc[i], o, 64) * bsc;
+    m = mn;
+  }
+  if (active && kl == 0) {
+    const float inv = 1.f / l;
+    f16* op = O + ((int64_t)b * n_q + qi) * ldo + h * HD;
+#pragma unroll
+    for (int i = 0; i < HD / 8; ++i) {
+      f16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (f16)(acc[8 * i + j] * inv);
+      *(f16x8*)(op + 8 * i) = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Two-stage query selection: key[s] = max_t logits[b,s,t]; indices of the K largest, in descending
 // order, ties -> lower index (torch.topk leaves tie order unspecified).  One 1024-thread workgroup
@@ -518,6 +592,26 @@ extern "C" int ink_attn_fewkeys(const void* Q, int64_t ldq, const void* K, int64
   } else if (head_dim == 16) {
     hipLaunchKernelGGL(attn_fewkeys_kernel<16>, grid, block, 0, s, (const f16*)Q, ldq, (const f16*)K, ldk,
                        (const f16*)V, ldv, B, n_q, n_k, n_heads, scale, blocked, (f16*)O, ldo);
+  } else {
+    return INK_ERR_ARG;
+  }
+  return ink_launch_status();
+}
+
+extern "C" int ink_attn_fewq(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                             int32_t n_batch, int32_t n_q, int32_t n_k, int32_t n_heads, int32_t head_dim,
+                             float scale, const int32_t* q_batch_rows, const int32_t* kv_batch_rows, void* O,
+                             int64_t ldo, void* stream) {
+  INK_CHECK_ARG(Q && K && V && O && n_batch > 0 && n_q > 0 && n_q <= 8 && n_k > 0 && n_heads > 0);
+  INK_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0);
+  const dim3 grid(n_batch * n_heads), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (head_dim == 16) {
+    hipLaunchKernelGGL(attn_fewq_kernel<16>, grid, block, 0, s, (const f16*)Q, ldq, (const f16*)K, ldk,
+                       (const f16*)V, ldv, n_q, n_k, n_heads, scale, q_batch_rows, kv_batch_rows, (f16*)O, ldo);
+  } else if (head_dim == 32) {
+    hipLaunchKernelGGL(attn_fewq_kernel<32>, grid, block, 0, s, (const f16*)Q, ldq, (const f16*)K, ldk,
+                       (const f16*)V, ldv, n_q, n_k, n_heads, scale, q_batch_rows, kv_batch_rows, (f16*)O, ldo);
   } else {
     return INK_ERR_ARG;
   }

@@ -14,6 +14,8 @@
 //     contiguous band of M-tiles and re-reads its A panel from L2.
 // Epilogue (fused, f32): +bias, GELU/ReLU, *col_scale, +residual, optional row
 // scatter (window-unpartition / crop / un-shift), f32 or f16 store.
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/inklayer_hip.h"
 
@@ -30,20 +32,29 @@ template <> struct Swz<32> {  // 64-B rows, 4 chunks
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BK>
-__global__ __launch_bounds__(256, 2) void gemm_f16_nt_128(InkGemm p) {
-  constexpr int BM = 128, BN = 128;
+// Generic tile: BM x BN output per workgroup, WM x WN waves (each (BM/WM) x (BN/WN)), K step BK,
+// NS LDS stages.  NS == 2: one K-tile in flight, plain __syncthreads (drains the DMA).
+// NS >= 3: NS-1 K-tiles in flight behind a COUNTED s_waitcnt vmcnt(N) + raw s_barrier
+// (cdna_hip_programming.md §5 "Pipelining across barriers"): the wait that retires tile kt comes
+// before the barrier, the reads of tile kt after it, and the buffer that is re-filled is the one read
+// in the previous iteration (every wave has passed this iteration's barrier, i.e. finished those reads).
+template <int BM, int BN, int BK, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p) {
+  constexpr int NT = WM * WN * 64;
   constexpr int CPR = BK / 8;          // 16-B chunks per tile row
   constexpr int ROWB = BK * 2;         // bytes per tile row
-  constexpr int TILE = BM * ROWB;      // bytes per operand tile
-  constexpr int STAGE = 2 * TILE;      // A tile + W tile
-  constexpr int ITERS = (BM * CPR) / 256;
+  constexpr int TILE_A = BM * ROWB, TILE_W = BN * ROWB;
+  constexpr int STAGE = TILE_A + TILE_W;
+  constexpr int IT_A = (BM * CPR) / NT, IT_W = (BN * CPR) / NT;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int LOADS = IT_A + IT_W;   // DMA instructions per thread per stage
+  static_assert((BM * CPR) % NT == 0 && (BN * CPR) % NT == 0, "tile/threads mismatch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
@@ -54,85 +65,102 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_nt_128(InkGemm p) {
   const f16* __restrict__ A = (const f16*)p.A;
   const f16* __restrict__ W = (const f16*)p.W;
 
-  // per-thread DMA source rows (constant over the K loop)
-  const f16* srcA[ITERS];
-  const f16* srcW[ITERS];
+  const f16* srcA[IT_A];
+  const f16* srcW[IT_W];
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int pch = it * 256 + tid;      // linear chunk index inside the tile image
+  for (int it = 0; it < IT_A; ++it) {
+    const int pch = it * NT + tid;
     const int row = pch / CPR;
-    const int lch = (pch % CPR) ^ Swz<BK>::f(row);  // logical chunk stored at this slot
-    const int ra = min(m0 + row, p.M - 1);
-    const int rw = min(n0 + row, p.N - 1);
-    srcA[it] = A + (size_t)ra * p.lda + lch * 8;
-    srcW[it] = W + (size_t)rw * p.ldw + lch * 8;
+    const int lch = (pch % CPR) ^ Swz<BK>::f(row);
+    srcA[it] = A + (size_t)min(m0 + row, p.M - 1) * p.lda + lch * 8;
+  }
+#pragma unroll
+  for (int it = 0; it < IT_W; ++it) {
+    const int pch = it * NT + tid;
+    const int row = pch / CPR;
+    const int lch = (pch % CPR) ^ Swz<BK>::f(row);
+    srcW[it] = W + (size_t)min(n0 + row, p.N - 1) * p.ldw + lch * 8;
   }
 
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE;
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      // wave-uniform LDS base; the DMA adds lane*16 itself
-      char* la = base + (it * 256 + wave * 64) * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[it] + kt * BK), (lptr_t)la, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[it] + kt * BK), (lptr_t)(la + TILE), 16, 0, 0);
+    for (int it = 0; it < IT_A; ++it)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[it] + kt * BK), (lptr_t)(base + (it * NT + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+    for (int it = 0; it < IT_W; ++it)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[it] + kt * BK), (lptr_t)(base + TILE_A + (it * NT + wave * 64) * 16), 16, 0, 0);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int offA = (wm * (BM / WM) + fr) * ROWB;
+  const int offW = (wn * (BN / WN) + fr) * ROWB;
+  const int swz = Swz<BK>::f(fr);      // tile-row bases are multiples of 16 -> swz depends on fr only
+
+  const int nk = p.K / BK;
+  auto compute = [&](int cur) {
+    const char* bA = smem + cur * STAGE;
+    const char* bW = bA + TILE_A;
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      f16x8 a[TM], w[TN];
+      const int co = ((kk * 4 + fq) ^ swz) << 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *(const f16x8*)(bA + offA + i * 16 * ROWB + co);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) w[j] = *(const f16x8*)(bW + offW + j * 16 * ROWB + co);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], a[i], acc[i][j], 0, 0, 0);
     }
   };
 
-  f32x4 acc[4][4];
+  if constexpr (NS == 2) {
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      compute(kt & 1);
+    }
+  } else {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offsets (bytes) within a tile, per k-step
-  const int fr = lane & 15, fq = lane >> 4;
-  int offA[4], offW[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = wm * 64 + i * 16 + fr;
-    const int rw = wn * 64 + i * 16 + fr;
-    offA[i] = ra * ROWB;
-    offW[i] = rw * ROWB;
-  }
-  const int swzA = Swz<BK>::f(wm * 64 + fr);  // swz depends on row & 15 only (tile bases are multiples of 16)
-  const int swzW = Swz<BK>::f(wn * 64 + fr);
-
-  const int nk = p.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    __syncthreads();  // tile kt has landed (vmcnt(0) + barrier); everyone is done reading buffer cur^1
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* bA = smem + cur * STAGE;
-    const char* bW = bA + TILE;
-#pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      f16x8 a[4], w[4];
-      const int lc = kk * 4 + fq;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = *(const f16x8*)(bA + offA[i] + ((lc ^ swzA) << 4));
-        w[i] = *(const f16x8*)(bW + offW[i] + ((lc ^ swzW) << 4));
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nk) stage(s, s);
+    int cur = 0, nxt = NS - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+      // tiles issued after kt and still wanted in flight: min(NS-2, nk-1-kt)
+      if (kt + NS - 2 < nk) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LOADS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], a[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + NS - 1 < nk) stage(nxt, kt + NS - 1);
+      compute(cur);
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      nxt = nxt + 1 == NS ? 0 : nxt + 1;
     }
   }
 
   // ---- epilogue: lane holds C[m = .. + fr][n = .. + 4*fq + 0..3] for each (i,j)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fr;
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / WM) + i * 16 + fr;
     if (m >= p.M) continue;
     const int orow = p.row_map ? p.row_map[m] : m;
     if (orow < 0) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fq * 4;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
       if (n >= p.N) continue;
       f32x4 v = acc[i][j];
       if (p.bias) v += *(const f32x4*)(p.bias + n);
@@ -155,9 +183,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_nt_128(InkGemm p) {
   }
 }
 
+template <int BM, int BN, int BK, int WM, int WN, int NS>
+static int launch_gemm(const InkGemm& p, hipStream_t s) {
+  constexpr int lds = NS * (BM + BN) * BK * 2;
+  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt<BM, BN, BK, WM, WN, NS>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+  (void)attr;
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_f16_nt<BM, BN, BK, WM, WN, NS>), dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, p);
+  return ink_launch_status();
+}
+
 }  // namespace
 
+static int g_variant = -1;
 extern "C" int ink_abi_version(void) { return INK_ABI_VERSION; }
+extern "C" int ink_gemm_set_variant(int32_t v) {
+  g_variant = v;
+  return INK_OK;
+}
 
 extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
   INK_CHECK_ARG(pp != nullptr);
@@ -171,18 +215,31 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
   INK_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0);
   INK_CHECK_ARG(((uintptr_t)p.C & 15) == 0);
   INK_CHECK_ARG(p.act >= 0 && p.act <= 2);
-  const int ntm = (p.M + 127) / 128, ntn = (p.N + 127) / 128;
-  const dim3 grid(ntm * ntn), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (p.K % 64 == 0) {
-    constexpr int lds = 2 * 2 * 128 * 64 * 2;
-    static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt_128<64>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
-    (void)attr;
-    hipLaunchKernelGGL(gemm_f16_nt_128<64>, grid, block, lds, s, p);
-  } else {
-    constexpr int lds = 2 * 2 * 128 * 32 * 2;
-    hipLaunchKernelGGL(gemm_f16_nt_128<32>, grid, block, lds, s, p);
+  static const int env_forced = getenv("INK_GEMM_VARIANT") ? atoi(getenv("INK_GEMM_VARIANT")) : -1;
+  int v = g_variant >= 0 ? g_variant : env_forced;
+  if (p.K % 64 != 0) return launch_gemm<128, 128, 32, 2, 2, 2>(p, s);
+  if (v < 0) {
+    // shape heuristic (tools/gemm_sweep.py on MI355X): the 16-wave 256x256 tile wins whenever it fills the
+    // chip (>= ~200 tiles) and N does not waste a large part of a 256-wide tile; else the 128x128 tile.
+    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const bool n_fits = (p.N % 256 == 0) || p.N >= 1024;
+    v = (tiles256 >= 200 && n_fits) ? 10 : 0;
   }
-  return ink_launch_status();
+  switch (v) {
+    case 1: return launch_gemm<128, 128, 64, 2, 2, 4>(p, s);     // 128 KB, 1 block/CU, 3 tiles in flight
+    case 2: return launch_gemm<256, 128, 64, 4, 2, 3>(p, s);     // 144 KB, 8 waves, 2 tiles in flight
+    case 3: return launch_gemm<128, 128, 32, 2, 2, 4>(p, s);     // 64 KB, 2 blocks/CU, 3 half-tiles in flight
+    case 4: return launch_gemm<256, 256, 64, 2, 4, 2>(p, s);     // 128 KB, 8 waves x (128x64)
+    case 5: return launch_gemm<128, 128, 64, 2, 2, 3>(p, s);     // 96 KB, 1 block/CU, 2 tiles in flight
+    case 6: return launch_gemm<256, 128, 32, 4, 2, 5>(p, s);     // 120 KB, 8 waves, 4 half-tiles in flight
+    case 7: return launch_gemm<256, 256, 32, 2, 4, 3>(p, s);     // 96 KB, 8 waves
+    case 8: return launch_gemm<256, 256, 32, 2, 4, 4>(p, s);     // 128 KB, 8 waves
+    case 9: return launch_gemm<256, 256, 64, 4, 2, 2>(p, s);     // 8 waves x (64x128)
+    case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s);    // 16 waves x (64x64)
+    case 11: return launch_gemm<256, 256, 32, 4, 4, 4>(p, s);    // 16 waves, 3 half-tiles in flight
+    case 12: return launch_gemm<128, 256, 64, 2, 4, 2>(p, s);    // 8 waves x (64x64), 96 KB
+    case 13: return launch_gemm<256, 128, 64, 4, 2, 2>(p, s);    // 8 waves x (64x64), 96 KB
+    default: return launch_gemm<128, 128, 64, 2, 2, 2>(p, s);    // round-1 kernel
+  }
 }

@@ -81,7 +81,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         e0.record()
         check(_lib.lib().ink_gemm_f16(C.byref(p), _stream()), "ink_gemm_f16")
         e1.record()
-        _GEMM_TRACE.append((2.0 * M * N * K, e0, e1))
+        _GEMM_TRACE.append((2.0 * M * N * K, e0, e1, (M, N, K, act or '-', 'res' if residual is not None else '-',
+                                                      'map' if row_map is not None else '-', 'f16' if p.c_f16 else 'f32')))
     return out
 
 
@@ -392,6 +393,19 @@ def attn_fewkeys(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, B: int, n
     check(_lib.lib().ink_attn_fewkeys(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
                                       v.stride(0), B, n_q, n_k, n_heads, head_dim, scale, _p(blocked),
                                       out.data_ptr(), out.stride(0), _stream()), "ink_attn_fewkeys")
+    return out
+
+
+def attn_fewq(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: int, n_heads: int, head_dim: int,
+              scale: float, n_q: int, n_k: int, q_batch_rows: Optional[torch.Tensor] = None,
+              kv_batch_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Few queries (<= 8) against many keys; same row conventions as flash_attn."""
+    for t in (q, k, v):
+        assert t.dtype == F16 and t.dim() == 2 and t.stride(1) == 1
+    out = torch.empty((n_batch * n_q, n_heads * head_dim), device=q.device, dtype=F16)
+    check(_lib.lib().ink_attn_fewq(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                   n_batch, n_q, n_k, n_heads, head_dim, scale, _p(q_batch_rows),
+                                   _p(kv_batch_rows), out.data_ptr(), out.stride(0), _stream()), "ink_attn_fewq")
     return out
 
 

@@ -273,8 +273,12 @@ class SamEngine:
         q = pre_q if pre_q is not None else ops.gemm(q16, w[name + ".q_proj.w"], w[name + ".q_proj.b"], out_dtype=F16)
         k = pre_k if pre_k is not None else ops.gemm(k16, w[name + ".k_proj.w"], w[name + ".k_proj.b"], out_dtype=F16)
         v = pre_v if pre_v is not None else ops.gemm(v16, w[name + ".v_proj.w"], w[name + ".v_proj.b"], out_dtype=F16)
-        a = ops.flash_attn(q, k, v, n_batch=n, n_heads=Hh, head_dim=hd, scale=1.0 / math.sqrt(hd),
-                           n_q=n_q, n_k=n_k, q_batch_rows=q_rows, kv_batch_rows=kv_rows)
+        if n_q <= 8 and n_k >= 256:      # tokens -> image: few queries, many keys
+            a = ops.attn_fewq(q, k, v, n_batch=n, n_heads=Hh, head_dim=hd, scale=1.0 / math.sqrt(hd), n_q=n_q,
+                              n_k=n_k, q_batch_rows=q_rows, kv_batch_rows=kv_rows)
+        else:
+            a = ops.flash_attn(q, k, v, n_batch=n, n_heads=Hh, head_dim=hd, scale=1.0 / math.sqrt(hd),
+                               n_q=n_q, n_k=n_k, q_batch_rows=q_rows, kv_batch_rows=kv_rows)
         return ops.gemm(a, w[name + ".out_proj.w"], w[name + ".out_proj.b"], residual=residual)
 
     def decode(self, emb: torch.Tensor, boxes_input_frame: np.ndarray | torch.Tensor,
