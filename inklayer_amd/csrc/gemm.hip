@@ -39,7 +39,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // before the barrier, the reads of tile kt after it, and the buffer that is re-filled is the one read
 // in the previous iteration (every wave has passed this iteration's barrier, i.e. finished those reads).
 template <int BM, int BN, int BK, int WM, int WN, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group_m) {
   constexpr int NT = WM * WN * 64;
   constexpr int CPR = BK / 8;          // 16-B chunks per tile row
   constexpr int ROWB = BK * 2;         // bytes per tile row
@@ -59,8 +59,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p) {
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (id / ntn) * BM;
-  const int n0 = (id % ntn) * BN;
+  // grouped order inside the XCD-contiguous id space: GM consecutive M-tiles x all N-tiles, M fastest, so the
+  // ~32 tiles an XCD runs concurrently share GM A-panels and 32/GM W-panels (L2 = 4 MiB per XCD)
+  int mt, nt;
+  if (group_m > 1) {
+    const int per = group_m * ntn;
+    const int first = (id / per) * group_m;
+    const int gsz = min(ntm - first, group_m);
+    mt = first + (id % per) % gsz;
+    nt = (id % per) / gsz;
+  } else {
+    mt = id / ntn;
+    nt = id % ntn;
+  }
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
 
   const f16* __restrict__ A = (const f16*)p.A;
   const f16* __restrict__ W = (const f16*)p.W;
@@ -184,13 +197,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NS>
-static int launch_gemm(const InkGemm& p, hipStream_t s) {
+static int launch_gemm(const InkGemm& p, hipStream_t s, int group_m = 1) {
   constexpr int lds = NS * (BM + BN) * BK * 2;
   static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt<BM, BN, BK, WM, WN, NS>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)attr;
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_f16_nt<BM, BN, BK, WM, WN, NS>), dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL((gemm_f16_nt<BM, BN, BK, WM, WN, NS>), dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, p, group_m);
   return ink_launch_status();
 }
 
@@ -218,6 +231,8 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   static const int env_forced = getenv("INK_GEMM_VARIANT") ? atoi(getenv("INK_GEMM_VARIANT")) : -1;
   int v = g_variant >= 0 ? g_variant : env_forced;
+  int gm = 1;
+  if (v >= 100) { gm = v / 100; v = v % 100; }
   if (p.K % 64 != 0) return launch_gemm<128, 128, 32, 2, 2, 2>(p, s);
   if (v < 0) {
     // shape heuristic (tools/gemm_sweep.py on MI355X): the 16-wave 256x256 tile wins whenever it fills the
@@ -225,6 +240,7 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     const bool n_fits = (p.N % 256 == 0) || p.N >= 1024;
     v = (tiles256 >= 200 && n_fits) ? 10 : 0;
+    gm = 4;
   }
   switch (v) {
     case 1: return launch_gemm<128, 128, 64, 2, 2, 4>(p, s);     // 128 KB, 1 block/CU, 3 tiles in flight
@@ -236,7 +252,7 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     case 7: return launch_gemm<256, 256, 32, 2, 4, 3>(p, s);     // 96 KB, 8 waves
     case 8: return launch_gemm<256, 256, 32, 2, 4, 4>(p, s);     // 128 KB, 8 waves
     case 9: return launch_gemm<256, 256, 64, 4, 2, 2>(p, s);     // 8 waves x (64x128)
-    case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s);    // 16 waves x (64x64)
+    case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s, gm);    // 16 waves x (64x64)
     case 11: return launch_gemm<256, 256, 32, 4, 4, 4>(p, s);    // 16 waves, 3 half-tiles in flight
     case 12: return launch_gemm<128, 256, 64, 2, 4, 2>(p, s);    // 8 waves x (64x64), 96 KB
     case 13: return launch_gemm<256, 128, 64, 4, 2, 2>(p, s);    // 8 waves x (64x64), 96 KB

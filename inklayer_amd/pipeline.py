@@ -16,6 +16,7 @@ import torch
 
 from . import gdino as gd
 from . import sam as sm
+from .ops import sam_postprocess as ops_sam_postprocess
 
 
 @dataclass
@@ -61,22 +62,51 @@ class InkLayerPipeline:
         dets = self.det.detect(det_in, top_n=top_n)
         emb = self.seg.encode(sam_in)
         L = self.seg.cfg.img_size
-        out = []
+        per_img, all_boxes, img_of_box = [], [], []
         for b, ((boxes_cxcywh, scores), ((oh, ow), (ih, iw))) in enumerate(zip(dets, sizes)):
             bx = boxes_cxcywh.double().numpy().reshape(-1, 4)
             xyxy = np.stack([bx[:, 0] - bx[:, 2] / 2, bx[:, 1] - bx[:, 3] / 2, bx[:, 0] + bx[:, 2] / 2,
                              bx[:, 1] + bx[:, 3] / 2], -1)
             pix = boxes_to_pixels(xyxy, ow, oh)
-            if len(pix) == 0:
-                masks = torch.zeros((0, oh, ow), dtype=torch.uint8, device=self.dev)
-            else:
+            per_img.append((xyxy, scores.numpy(), pix))
+            if len(pix):
                 # ResizeLongestSide.apply_boxes_torch (SA/utils/transforms.py:67-91)
                 nh, nw = sm.preprocess_shape(oh, ow, L)
                 tb = pix.reshape(-1, 2, 2).clone()
                 tb[..., 0] = tb[..., 0] * (nw / ow)
                 tb[..., 1] = tb[..., 1] * (nh / oh)
-                masks = self.seg.decode(emb[b], tb.reshape(-1, 4), (ih, iw), (oh, ow))
-            out.append(SketchResult(xyxy, scores.numpy(), pix, masks))
+                all_boxes.append(tb.reshape(-1, 4))
+                img_of_box += [b] * len(pix)
+        # prompt encoder + mask decoder for ALL boxes of the batch in one pass
+        low = None
+        if img_of_box:
+            low, _ = self.seg.decode_low_res(emb, torch.cat(all_boxes, 0), img_of_box)
+        out, off = [], 0
+        thr = self.seg.cfg.mask_threshold
+        # postprocess: one launch per run of images that share (input size, original size)
+        groups = []
+        for b, (xyxy, sc, pix) in enumerate(per_img):
+            n = len(pix)
+            key = sizes[b]
+            if groups and groups[-1][0] == key:
+                groups[-1][2].append((b, n))
+                groups[-1][1][1] += n
+            else:
+                groups.append([key, [off, n], [(b, n)]])
+            off += n
+        masks_per_img = {}
+        for (oh_ow, ih_iw), (start, cnt), members in groups:
+            if cnt == 0:
+                for b, n in members:
+                    masks_per_img[b] = torch.zeros((0, oh_ow[0], oh_ow[1]), dtype=torch.uint8, device=self.dev)
+                continue
+            m = ops_sam_postprocess(low[start:start + cnt], L, ih_iw, oh_ow, thr)
+            o = 0
+            for b, n in members:
+                masks_per_img[b] = m[o:o + n]
+                o += n
+        for b, (xyxy, sc, pix) in enumerate(per_img):
+            out.append(SketchResult(xyxy, sc, pix, masks_per_img[b]))
         return out
 
     def run_batch(self, images_rgb: Sequence[np.ndarray], top_n: Optional[int] = None) -> List[SketchResult]:

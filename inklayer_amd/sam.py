@@ -286,11 +286,23 @@ class SamEngine:
         """One image: emb [4096, 256] f32 tokens, boxes [n, 4] xyxy in the resized-input frame
         (host memory).  PromptEncoder + MaskDecoder(multimask_output=False) + postprocess.
         Returns uint8 masks [n, H, W] on the GPU (+ low-res logits, iou, full logits if asked)."""
+        boxes = torch.as_tensor(np.asarray(boxes_input_frame), dtype=torch.float32).reshape(-1, 4)
+        low, iou = self.decode_low_res(emb.reshape(1, self.T, -1), boxes, [0] * boxes.shape[0])
+        res = ops.sam_postprocess(low, self.cfg.img_size, input_hw, orig_hw, self.cfg.mask_threshold, want_logits)
+        if want_logits:
+            return res[0], low, iou, res[1]
+        return res
+
+    def decode_low_res(self, emb: torch.Tensor, boxes: torch.Tensor, img_of_box: Sequence[int]):
+        """Prompt encoder + mask decoder for N boxes spread over B images in ONE pass (the reference decodes
+        one image at a time; batching only changes which rows share a launch).  emb [B, 4096, 256] f32,
+        boxes [N, 4] xyxy in the resized-input frame (host), img_of_box[i] = image of box i.
+        -> (low-res logits [N, 256, 256] f32, iou [N, 1] f32)."""
         cfg, w, T, dev = self.cfg, self.w, self.T, self.dev
         E, L, g = cfg.prompt_embed_dim, cfg.img_size, cfg.grid
-        boxes = torch.as_tensor(np.asarray(boxes_input_frame), dtype=torch.float32).reshape(-1, 4)
+        B = emb.shape[0]
         n = boxes.shape[0]
-        assert n > 0
+        assert n > 0 and len(img_of_box) == n
         NT = 5 + 2                                         # iou + 4 mask tokens + 2 box corners
         # --- prompt encoder (_embed_boxes): host-side affine of 4n numbers, Fourier features on GPU
         coords = ((boxes + 0.5).reshape(-1, 2) / float(L)).contiguous().to(dev)
@@ -299,10 +311,11 @@ class SamEngine:
         tokens[:, :5] = w["out_tok"]                       # plumbing copies (no math)
         tokens[:, 5:] = sparse.view(n, 2, E)
         qpe = tokens.view(n * NT, E)
-        zero_rows = torch.zeros(n, dtype=torch.int32, device=dev)
+        iob = torch.as_tensor(list(img_of_box), dtype=torch.int64)
+        img_rows = (iob * T).to(torch.int32).to(dev)       # first key row of each box's image
 
-        # --- image side, shared by all boxes: src = emb + no_mask_embed; key_pe = dense PE
-        keys0 = ops.add_f32(emb.reshape(T, E).contiguous(), w["no_mask"])          # [T, E]
+        # --- image side, shared by all boxes of an image: src = emb + no_mask_embed; key_pe = dense PE
+        keys0 = ops.add_f32(emb.reshape(B * T, E).contiguous(), w["no_mask"])      # [B*T, E]
         kpe = self.dense_pe
         queries = qpe
         keys = None                                        # per-box keys [n*T, E] after layer 0
@@ -325,7 +338,7 @@ class SamEngine:
             if keys is None:
                 k16 = ops.add_cvt_f16(keys0, kpe)
                 v16 = ops.add_cvt_f16(keys0)
-                att = self._dec_attn(d + ".t2i", q16, k16, v16, n, NT, T, 16, queries, kv_rows=zero_rows)
+                att = self._dec_attn(d + ".t2i", q16, k16, v16, n, NT, T, 16, queries, kv_rows=img_rows)
             else:
                 k16 = ops.add_cvt_f16(keys, kpe)
                 v16 = ops.add_cvt_f16(keys)
@@ -340,8 +353,9 @@ class SamEngine:
             tk16 = ops.add_cvt_f16(queries, qpe)
             tv16 = ops.add_cvt_f16(queries)
             if keys is None:
-                keys = ops.add_f32(torch.empty((n, T, E), device=dev, dtype=F32).zero_().view(n * T, E), keys0)
-                att = self._dec_attn(d + ".i2t", k16, tk16, tv16, n, T, NT, 16, keys, q_rows=zero_rows)
+                # per-box copy of the image keys (repeat_interleave of mask_decoder.py:124; a pure memory copy)
+                keys = keys0.view(B, T * E).index_select(0, iob.to(dev)).view(n * T, E)
+                att = self._dec_attn(d + ".i2t", k16, tk16, tv16, n, T, NT, 16, keys, q_rows=img_rows)
             else:
                 att = self._dec_attn(d + ".i2t", k16, tk16, tv16, n, T, NT, 16, keys)
             keys = ops.layernorm_rows(att, w[d + ".norm4.w"], w[d + ".norm4.b"], 1e-5, out_dtype=F32)
@@ -364,10 +378,7 @@ class SamEngine:
         u1 = ops.layernorm_rows(u0.view(n * T * 4, E // 4), w["up1.w"], w["up1.b"], 1e-6, act="gelu")
         u2 = ops.gemm(u1, w["up3.w"], w["up3.b"], act="gelu")                     # [n*T*4, 4*32]
         low = ops.sam_mask_logits(u2, hyper.contiguous(), n, g)                   # [n, 256, 256]
-        res = ops.sam_postprocess(low, L, input_hw, orig_hw, cfg.mask_threshold, want_logits)
-        if want_logits:
-            return res[0], low, iou, res[1]
-        return res
+        return low, iou
 
 
 # ----------------------------------------------------------------------------------------
