@@ -246,9 +246,11 @@ int ink_attn_fewq(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
                   void* stream);
 
 /* Two-stage query selection (transformer.py:293-300): indices of the K largest max_t logits[b,s,t],
- * descending, ties -> lower index.  logits f32 [B,S,T], S <= 16384; out_idx int32 [B,K]. */
+ * descending, ties -> lower index.  logits f32 [B,S,T]; out_idx int32 [B,K].  S <= 16384 is one LDS
+ * bitonic sort per image; larger S (800x1333 inputs give 22223 tokens) sorts ceil(S/16384) equal chunks and
+ * merges their K best: cand_ws must then hold B * nchunk * K uint64. */
 int ink_topk_rowmax(const float* logits, int32_t B, int32_t S, int32_t T, int32_t K, int32_t* out_idx,
-                    float* out_val, void* stream);
+                    float* out_val, void* cand_ws, void* stream);
 
 /* gen_sineembed_for_position (GD/.../utils.py:204-230) for boxes ref f32 [N,4] -> f16 [N,512];
  * dim_t f32 [128] = 10000^(2*(i//2)/128). */

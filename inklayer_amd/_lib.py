@@ -71,7 +71,7 @@ SIGNATURES = {
                          c_float, c_void_p, c_void_p, c_i64, c_void_p],
     "ink_attn_fewq": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int,
                       c_float, c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
-    "ink_topk_rowmax": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "ink_topk_rowmax": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ink_sine_embed4": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "ink_box_refine": [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "ink_relpos_bias": [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,

@@ -429,25 +429,7 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const f16* __restrict__ 
 // Two-stage query selection: key[s] = max_t logits[b,s,t]; indices of the K largest, in descending
 // order, ties -> lower index (torch.topk leaves tie order unspecified).  One 1024-thread workgroup
 // per image, bitonic sort of 64-bit (ordered-value, index) keys in LDS (S <= 16384 -> 128 KiB).
-__global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ logits, int S, int T, int K,
-                                                    int NP, int32_t* __restrict__ out_idx,
-                                                    float* __restrict__ out_val) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* keys = (unsigned long long*)smem;
-  const int b = blockIdx.x;
-  const float* lp = logits + (int64_t)b * S * T;
-  for (int i = threadIdx.x; i < NP; i += 1024) {
-    unsigned long long k = ~0ull;
-    if (i < S) {
-      float v = lp[(int64_t)i * T];
-      for (int t = 1; t < T; ++t) v = fmaxf(v, lp[(int64_t)i * T + t]);
-      unsigned u = __float_as_uint(v);
-      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // monotone float -> uint
-      k = ((unsigned long long)(~u) << 32) | (unsigned)i;  // ascending key == descending value, then index
-    }
-    keys[i] = k;
-  }
-  __syncthreads();
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* keys, int NP) {
   for (int size = 2; size <= NP; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int i = threadIdx.x; i < NP / 2; i += 1024) {
@@ -460,6 +442,9 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ lo
       __syncthreads();
     }
   }
+}
+__device__ __forceinline__ void emit_topk(const unsigned long long* keys, int K, int b, int32_t* out_idx,
+                                          float* out_val) {
   for (int i = threadIdx.x; i < K; i += 1024) {
     const unsigned long long k = keys[i];
     out_idx[(int64_t)b * K + i] = (int)(k & 0xffffffffu);
@@ -469,6 +454,48 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ lo
       out_val[(int64_t)b * K + i] = __uint_as_float(u);
     }
   }
+}
+// pass 1: grid (B, nchunk); each workgroup sorts one chunk of <= 16384 tokens and keeps its K best keys
+// (nchunk == 1: writes the final result directly)
+__global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ logits, int S, int T, int K,
+                                                    int chunk, int NP, unsigned long long* __restrict__ cand,
+                                                    int32_t* __restrict__ out_idx, float* __restrict__ out_val) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = (unsigned long long*)smem;
+  const int b = blockIdx.x, c = blockIdx.y, nchunk = gridDim.y;
+  const float* lp = logits + (int64_t)b * S * T;
+  const int s0 = c * chunk, s1 = min(S, s0 + chunk);
+  for (int i = threadIdx.x; i < NP; i += 1024) {
+    unsigned long long k = ~0ull;
+    const int sidx = s0 + i;
+    if (sidx < s1) {
+      float v = lp[(int64_t)sidx * T];
+      for (int t = 1; t < T; ++t) v = fmaxf(v, lp[(int64_t)sidx * T + t]);
+      unsigned u = __float_as_uint(v);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // monotone float -> uint
+      k = ((unsigned long long)(~u) << 32) | (unsigned)sidx;  // ascending key == descending value, then index
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  bitonic_sort_lds(keys, NP);
+  if (nchunk == 1) {
+    emit_topk(keys, K, b, out_idx, out_val);
+  } else {
+    for (int i = threadIdx.x; i < K; i += 1024) cand[((int64_t)b * nchunk + c) * K + i] = keys[i];
+  }
+}
+// pass 2: merge the nchunk * K candidates of one image
+__global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long long* __restrict__ cand, int n,
+                                                          int K, int NP, int32_t* __restrict__ out_idx,
+                                                          float* __restrict__ out_val) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = (unsigned long long*)smem;
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < NP; i += 1024) keys[i] = i < n ? cand[(int64_t)b * n + i] : ~0ull;
+  __syncthreads();
+  bitonic_sort_lds(keys, NP);
+  emit_topk(keys, K, b, out_idx, out_val);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -619,16 +646,31 @@ extern "C" int ink_attn_fewq(const void* Q, int64_t ldq, const void* K, int64_t 
 }
 
 extern "C" int ink_topk_rowmax(const float* logits, int32_t B, int32_t S, int32_t T, int32_t K,
-                               int32_t* out_idx, float* out_val, void* stream) {
-  INK_CHECK_ARG(logits && out_idx && B > 0 && S > 0 && T > 0 && K > 0 && K <= S && S <= 16384);
-  int NP = 2;
-  while (NP < S) NP <<= 1;
-  const int lds = NP * 8;
-  static bool attr = ((void)hipFuncSetAttribute((const void*)topk_kernel,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8), true);
+                               int32_t* out_idx, float* out_val, void* cand_ws, void* stream) {
+  constexpr int CHUNK = 16384;
+  INK_CHECK_ARG(logits && out_idx && B > 0 && S > 0 && T > 0 && K > 0 && K <= S);
+  const int nchunk = (S + CHUNK - 1) / CHUNK;
+  INK_CHECK_ARG(nchunk == 1 || (cand_ws && K <= CHUNK / 2 && S - (nchunk - 1) * CHUNK >= 0 && nchunk * K <= 16384));
+  INK_CHECK_ARG(nchunk == 1 || S / nchunk >= K);   // every chunk must hold at least K tokens
+  static bool attr = ((void)hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                CHUNK * 8),
+                      (void)hipFuncSetAttribute((const void*)topk_merge_kernel,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * 8), true);
   (void)attr;
-  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, logits, S, T, K, NP, out_idx,
-                     out_val);
+  hipStream_t s = (hipStream_t)stream;
+  // equal chunks so that each one has >= K tokens
+  const int chunk = (S + nchunk - 1) / nchunk;
+  int NP = 2;
+  while (NP < chunk) NP <<= 1;
+  hipLaunchKernelGGL(topk_kernel, dim3(B, nchunk), dim3(1024), NP * 8, s, logits, S, T, K, chunk, NP,
+                     (unsigned long long*)cand_ws, out_idx, out_val);
+  if (nchunk > 1) {
+    const int n = nchunk * K;
+    int NP2 = 2;
+    while (NP2 < n) NP2 <<= 1;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(1024), NP2 * 8, s, (const unsigned long long*)cand_ws, n, K,
+                       NP2, out_idx, out_val);
+  }
   return ink_launch_status();
 }
 

@@ -38,7 +38,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // (cdna_hip_programming.md §5 "Pipelining across barriers"): the wait that retires tile kt comes
 // before the barrier, the reads of tile kt after it, and the buffer that is re-filled is the one read
 // in the previous iteration (every wave has passed this iteration's barrier, i.e. finished those reads).
-template <int BM, int BN, int BK, int WM, int WN, int NS>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group_m) {
   constexpr int NT = WM * WN * 64;
   constexpr int CPR = BK / 8;          // 16-B chunks per tile row
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();
-      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-      compute(kt & 1);
+      if (kt + 1 < nk && (ABL != 1 || kt == 0)) stage((kt + 1) & 1, kt + 1);
+      if (ABL != 2 || kt + 1 == nk) compute(kt & 1);
     }
   } else {
 #pragma unroll
@@ -196,14 +196,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int ABL = 0>
 static int launch_gemm(const InkGemm& p, hipStream_t s, int group_m = 1) {
   constexpr int lds = NS * (BM + BN) * BK * 2;
-  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt<BM, BN, BK, WM, WN, NS>,
+  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt<BM, BN, BK, WM, WN, NS, ABL>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)attr;
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_f16_nt<BM, BN, BK, WM, WN, NS>), dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, p, group_m);
+  hipLaunchKernelGGL((gemm_f16_nt<BM, BN, BK, WM, WN, NS, ABL>), dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, p, group_m);
   return ink_launch_status();
 }
 
@@ -253,7 +253,13 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     case 8: return launch_gemm<256, 256, 32, 2, 4, 4>(p, s);     // 128 KB, 8 waves
     case 9: return launch_gemm<256, 256, 64, 4, 2, 2>(p, s);     // 8 waves x (64x128)
     case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s, gm);    // 16 waves x (64x64)
+    case 21: return launch_gemm<256, 256, 64, 4, 4, 2, 1>(p, s, gm);  // ablation: no DMA after tile 1
+    case 22: return launch_gemm<256, 256, 64, 4, 4, 2, 2>(p, s, gm);  // ablation: no MFMA
     case 11: return launch_gemm<256, 256, 32, 4, 4, 4>(p, s);    // 16 waves, 3 half-tiles in flight
+    case 14: return launch_gemm<256, 128, 32, 4, 2, 2>(p, s, gm);    // 48 KB: 2-3 blocks/CU, 8 waves x (64x64)
+    case 15: return launch_gemm<128, 256, 32, 2, 4, 2>(p, s, gm);
+    case 16: return launch_gemm<128, 128, 64, 2, 2, 2>(p, s, gm);    // v0 with grouping
+    case 17: return launch_gemm<256, 128, 32, 4, 2, 3>(p, s, gm);    // 72 KB: 2 blocks/CU, 2 half-tiles in flight
     case 12: return launch_gemm<128, 256, 64, 2, 4, 2>(p, s);    // 8 waves x (64x64), 96 KB
     case 13: return launch_gemm<256, 128, 64, 4, 2, 2>(p, s);    // 8 waves x (64x64), 96 KB
     default: return launch_gemm<128, 128, 64, 2, 2, 2>(p, s);    // round-1 kernel

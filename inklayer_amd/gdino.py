@@ -540,6 +540,10 @@ class GDinoEngine:
         (`.cpu().sigmoid()`): 900 x (T+4) floats per image cross PCIe in ONE copy."""
         logits, boxes = self.forward(images_u8)
         both = torch.cat([logits, boxes], dim=-1).cpu()       # single D2H copy
+        return self.postprocess(both, top_n)
+
+    def postprocess(self, both: torch.Tensor, top_n: Optional[int] = None):
+        """Host half of predict(): `both` = cat(logits, boxes) [B, nq, T+4] on the CPU."""
         T = self.T
         res = []
         for b in range(both.shape[0]):

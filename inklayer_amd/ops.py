@@ -415,7 +415,9 @@ def topk_rowmax(logits: torch.Tensor, K: int, want_values: bool = False):
     B, S, T = logits.shape
     idx = torch.empty((B, K), device=logits.device, dtype=torch.int32)
     val = torch.empty((B, K), device=logits.device, dtype=F32) if want_values else None
-    check(_lib.lib().ink_topk_rowmax(logits.data_ptr(), B, S, T, K, idx.data_ptr(), _p(val), _stream()),
+    nchunk = -(-S // 16384)
+    ws = torch.empty((B * nchunk * K,), device=logits.device, dtype=torch.int64) if nchunk > 1 else None
+    check(_lib.lib().ink_topk_rowmax(logits.data_ptr(), B, S, T, K, idx.data_ptr(), _p(val), _p(ws), _stream()),
           "ink_topk_rowmax")
     return (idx, val) if want_values else idx
 

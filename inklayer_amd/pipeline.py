@@ -40,10 +40,24 @@ def boxes_to_pixels(norm_xyxy: np.ndarray, W: int, H: int) -> torch.Tensor:
     return b
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class InkLayerPipeline:
-    def __init__(self, detector: gd.GDinoEngine, segmentor: sm.SamEngine):
+    def __init__(self, detector: gd.GDinoEngine, segmentor: sm.SamEngine, overlap: bool = True):
         self.det, self.seg = detector, segmentor
         self.dev = detector.dev
+        # The detector and the SAM image encoder are independent until the mask decoder needs the boxes:
+        # they run on two HIP streams.  The encoder's big GEMMs hold 16 of a CU's 32 wave slots and 128 of its
+        # 160 KB LDS, so the detector's many small latency-bound kernels co-reside instead of queueing.
+        self.overlap = overlap
+        self.s_det = torch.cuda.Stream(device=self.dev) if overlap else None
+        self.s_seg = torch.cuda.Stream(device=self.dev) if overlap else None
 
     def prepare(self, images_rgb: Sequence[np.ndarray]):
         """Host side: the two PIL resizes of the reference (800 shorter side for the detector,
@@ -59,8 +73,37 @@ class InkLayerPipeline:
 
     @torch.no_grad()
     def run_prepared(self, det_in, sam_in, sizes, top_n: Optional[int] = None) -> List[SketchResult]:
-        dets = self.det.detect(det_in, top_n=top_n)
-        emb = self.seg.encode(sam_in)
+        if self.overlap:
+            cur = torch.cuda.current_stream(self.dev)
+            self.s_det.wait_stream(cur)
+            self.s_seg.wait_stream(cur)
+            with torch.cuda.stream(self.s_det):
+                logits, boxes = self.det.forward(det_in)
+                both = torch.cat([logits, boxes], dim=-1)
+                host = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
+                host.copy_(both, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.s_det)
+            with torch.cuda.stream(self.s_seg):
+                emb = self.seg.encode(sam_in)
+            ev.synchronize()                               # host needs the boxes; the encoder keeps running
+            dets = self.det.postprocess(host, top_n=top_n)
+            stream_ctx = torch.cuda.stream(self.s_seg)
+        else:
+            dets = self.det.detect(det_in, top_n=top_n)
+            emb = self.seg.encode(sam_in)
+            stream_ctx = _NullCtx()
+        with stream_ctx:
+            out = self._decode_all(dets, emb, sizes)
+        if self.overlap:
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_stream(self.s_seg)
+            cur.wait_stream(self.s_det)
+            for r in out:                                  # results are consumed on the caller's stream
+                r.masks.record_stream(cur)
+        return out
+
+    def _decode_all(self, dets, emb, sizes) -> List[SketchResult]:
         L = self.seg.cfg.img_size
         per_img, all_boxes, img_of_box = [], [], []
         for b, ((boxes_cxcywh, scores), ((oh, ow), (ih, iw))) in enumerate(zip(dets, sizes)):

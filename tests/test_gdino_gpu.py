@@ -57,6 +57,12 @@ def test_topk_rowmax(dev):
     ref = torch.sort(key, dim=1, descending=True, stable=True)
     assert torch.equal(idx.cpu().long(), ref[1][:, :900])
     assert torch.equal(val.cpu(), ref[0][:, :900])
+    # > 16384 tokens (800x1333 inputs: 22223): two-level path, incl. ties that straddle the chunk boundary
+    y = torch.randn(2, 22223, 4, generator=g)
+    y[0, 11000:11300] = 3.5
+    idx = ops.topk_rowmax(y.to(dev), 900)
+    ref = torch.sort(y.max(-1)[0], dim=1, descending=True, stable=True)
+    assert torch.equal(idx.cpu().long(), ref[1][:, :900])
 
 
 def test_fusion_fewkeys_groupnorm_ops(dev):

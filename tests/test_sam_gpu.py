@@ -129,3 +129,20 @@ def test_run_sam_plugin_matches_oracle(dev, small_vith):
     print("run_SAM IoU:", ious)
     assert min(ious) > 0.99
     assert sam.run_SAM(Image.fromarray(img), torch.zeros((0, 4)), engine=eng) == []
+
+
+@torch.no_grad()
+def test_pipeline_two_stream_overlap_equals_serial(dev, small_vith):
+    """Detector + SAM encoder on two HIP streams must give bit-identical results to the serial order."""
+    from inklayer_amd import gdino, pipeline, weights_init
+    sd, oc, eng = small_vith
+    gcfg = gdino.GDinoConfig(enc_layers=1, dec_layers=1, num_queries=100)
+    det = gdino.GDinoEngine(weights_init.random_gdino_state_dict(gcfg, dev, 5), gcfg, dev,
+                            encoded_text=weights_init.random_text_features(gcfg, dev))
+    imgs = [_sketch(7, 600, 800), _sketch(8, 600, 800)]
+    a = pipeline.InkLayerPipeline(det, eng, overlap=True).run_batch(imgs, top_n=5)
+    b = pipeline.InkLayerPipeline(det, eng, overlap=False).run_batch(imgs, top_n=5)
+    torch.cuda.synchronize()
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra.boxes_xyxy_norm, rb.boxes_xyxy_norm) and torch.equal(ra.masks, rb.masks)
+        assert ra.masks.shape == (5, 600, 800) and ra.masks.dtype == torch.uint8
