@@ -437,6 +437,96 @@ __global__ __launch_bounds__(256) void relpos_kernel(const f16* __restrict__ Q, 
   }
 }
 
+
+// MFMA form of the same terms: D[r][q] = sum_d Tab[r][d] * Q[q][d] for the stacked tables
+// Tab = [rel_pos_h (2S-1 rows, padded to RT*32) ; rel_pos_w (same)], then a scattered store
+// out[q][j] = D[q_x - j + S - 1][q].  One workgroup per (batch*head, block of QB*32 queries); the table is
+// converted to f16 once into LDS (A operand via ds_read_b128), Q^T fragments come straight from HBM.
+template <int HD, int S, bool AUG>
+__global__ __launch_bounds__(256) void relpos_mfma_kernel(const f16* __restrict__ Q, int64_t ldq,
+                                                          const float* __restrict__ Rh,
+                                                          const float* __restrict__ Rw, int n_heads,
+                                                          float inv_scale, float* __restrict__ out_h,
+                                                          float* __restrict__ out_w, f16* __restrict__ out_aug) {
+  constexpr int NQ = S * S;
+  constexpr int RT = (2 * S - 1 + 31) / 32;       // 32-row tiles per table: 1 (S=14) or 4 (S=64)
+  constexpr int ROWS = 2 * RT * 32;
+  constexpr int TROW = (HD / 8 + 1) * 16;         // 176 B: odd number of 16-B chunks -> conflict-free b128
+  constexpr int NQG = (NQ + 31) / 32;             // 32-query groups per (batch, head)
+  constexpr int GPB = AUG ? NQG : 8;              // groups per workgroup (all 7 for a window; 8 of 128 global)
+  // per-wave output tile: [32 queries][AUG ? 32 f16 : 64 f32] (+16 B row pad), so that the scattered D elements
+  // land in LDS and HBM only ever sees whole-row 16-B stores
+  constexpr int OROW = (AUG ? 64 : 256) + 16;
+  __shared__ __attribute__((aligned(16))) char tab[ROWS * TROW + 4 * 32 * OROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, hh = lane >> 5;
+  char* ot = tab + ROWS * TROW + wave * 32 * OROW;
+  const int nblk = (NQG + GPB - 1) / GPB;
+  const int bh = blockIdx.x / nblk, gb = blockIdx.x % nblk;
+  const int b = bh / n_heads, h = bh % n_heads;
+  for (int i = tid; i < ROWS * (HD / 8); i += 256) {
+    const int r = i / (HD / 8), c8 = i % (HD / 8);
+    const int tr = r % (RT * 32);
+    const float* src = (r < RT * 32 ? Rh : Rw) + (int64_t)tr * HD + c8 * 8;
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tr < 2 * S - 1) {
+      const f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + 4);
+      v = (f16x8){(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)c[0], (f16)c[1], (f16)c[2], (f16)c[3]};
+    }
+    *(f16x8*)(tab + r * TROW + c8 * 16) = v;
+  }
+  __syncthreads();
+  for (int g = gb * GPB + wave; g < min(NQG, (gb + 1) * GPB); g += 4) {
+    const int q = g * 32 + lq;
+    const bool q_ok = q < NQ;
+    const int qc = q_ok ? q : NQ - 1;
+    const f16* qp = Q + ((int64_t)b * NQ + qc) * ldq + h * HD;
+    f16x8 qf[HD / 16];
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) qf[s] = *(const f16x8*)(qp + 16 * s + 8 * hh);
+    const int qh = qc / S, qw = qc % S;
+    if (AUG && hh == 0) *(f16x4*)(ot + lq * OROW + 56) = (f16x4){0, 0, 0, 0};   // cols 28..31
+#pragma unroll
+    for (int tt = 0; tt < 2 * RT; ++tt) {
+      f32x16 d;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < HD / 16; ++s) {
+        const f16x8 a = *(const f16x8*)(tab + (tt * 32 + lq) * TROW + (2 * s + hh) * 16);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], d, 0, 0, 0);
+      }
+      const bool is_w = tt >= RT;
+      const int base = (is_w ? qw : qh) + S - 1 - (tt % RT) * 32;   // j = base - (row within this tile)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = base - ((r & 3) + 8 * (r >> 2) + 4 * hh);
+        if (j >= 0 && j < S) {
+          const float v = d[r] * inv_scale;
+          if (AUG) {
+            *(f16*)(ot + lq * OROW + ((is_w ? S : 0) + j) * 2) = (f16)v;
+          } else {
+            *(float*)(ot + lq * OROW + j * 4) = v;
+          }
+        }
+      }
+      if (!AUG && (tt % RT) == RT - 1) {
+        // one table done for these 32 queries: rows of 64 f32 -> lane (q, hh) stores its 128-B half row
+        float* dst = (is_w ? out_w : out_h) + ((int64_t)bh * NQ + q) * S + hh * 32;
+        if (q_ok) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) *(f32x4*)(dst + 4 * i) = *(const f32x4*)(ot + lq * OROW + hh * 128 + i * 16);
+        }
+      }
+    }
+    if (AUG && q_ok) {
+      f16* dst = out_aug + ((int64_t)bh * NQ + q) * 32 + hh * 16;
+      *(f16x8*)dst = *(const f16x8*)(ot + lq * OROW + hh * 32);
+      *(f16x8*)(dst + 8) = *(const f16x8*)(ot + lq * OROW + hh * 32 + 16);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
@@ -500,15 +590,11 @@ extern "C" int ink_relpos_bias(const void* Q, int64_t ldq, const float* rel_pos_
   const int nbh = n_batch * n_heads;
   if (out_aug_f16) {
     INK_CHECK_ARG(S == 14);
-    const int waves = 2 * 14 * ((nbh + 3) / 4);
-    hipLaunchKernelGGL((relpos_kernel<80, 14, true>), dim3((waves + 3) / 4), dim3(256), 0, st, q, ldq,
-                       rel_pos_h, rel_pos_w, n_batch, n_heads, 1.0f / scale, out_h, out_w,
-                       (f16*)out_aug_f16);
+    hipLaunchKernelGGL((relpos_mfma_kernel<80, 14, true>), dim3(nbh), dim3(256), 0, st, q, ldq, rel_pos_h,
+                       rel_pos_w, n_heads, 1.0f / scale, out_h, out_w, (f16*)out_aug_f16);
   } else {
-    const int waves = 2 * 64 * nbh;
-    hipLaunchKernelGGL((relpos_kernel<80, 64, false>), dim3((waves + 3) / 4), dim3(256), 0, st, q, ldq,
-                       rel_pos_h, rel_pos_w, n_batch, n_heads, 1.0f / scale, out_h, out_w,
-                       (f16*)nullptr);
+    hipLaunchKernelGGL((relpos_mfma_kernel<80, 64, false>), dim3(nbh * 16), dim3(256), 0, st, q, ldq, rel_pos_h,
+                       rel_pos_w, n_heads, 1.0f / scale, out_h, out_w, (f16*)nullptr);
   }
   return ink_launch_status();
 }

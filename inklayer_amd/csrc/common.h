@@ -38,9 +38,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// exact (erf) GELU, as torch.nn.GELU() default
+// erf-form GELU, as torch.nn.GELU() default.  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e.
+// f32-rounding level for GELU's use) with v_rcp / v_exp: branch-free, ~12 VALU ops instead of libm's erff.
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float e = pl * t * __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);   // 1 - erf(|z|)
+  const float erf_abs = 1.0f - e;
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
 // bijective XCD-aware block remap: blocks b and b+8 share an XCD (round-robin

@@ -223,22 +223,24 @@ __global__ __launch_bounds__(256) void biattn_image_kernel(const f16* __restrict
   }
 }
 
-// text side, pass 1: per (b, h, t) max and sum-exp over the S image tokens (softmax over s).
-__global__ __launch_bounds__(256) void biattn_colstats_kernel(const float* __restrict__ scores, int S, int HT,
-                                                              float* __restrict__ stats) {
-  const int b = blockIdx.x;
+// text side, pass 1a: per (b, row-chunk): partial max / sum-exp of every (h, t) column over the chunk's rows
+__global__ __launch_bounds__(256) void biattn_colstats_partial_kernel(const float* __restrict__ scores, int S,
+                                                                      int HT, int rows_per_chunk,
+                                                                      float* __restrict__ part) {
+  const int c = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
   const float* sp = scores + (int64_t)b * S * HT;
-  __shared__ float red[4][16];
+  const int s0 = c * rows_per_chunk, s1 = min(S, s0 + rows_per_chunk);
+  __shared__ float red[4][2];
   float mx[16], sm[16];
-  for (int c = 0; c < HT; ++c) { mx[c] = -3.0e38f; sm[c] = 0.f; }
-  for (int s = threadIdx.x; s < S; s += 256)
-    for (int c = 0; c < HT; ++c) {
-      const float v = sp[(int64_t)s * HT + c];
-      if (v > mx[c]) { sm[c] = sm[c] * expf(mx[c] - v) + 1.f; mx[c] = v; } else { sm[c] += expf(v - mx[c]); }
+  for (int k = 0; k < HT; ++k) { mx[k] = -3.0e38f; sm[k] = 0.f; }
+  for (int s = s0 + threadIdx.x; s < s1; s += 256)
+    for (int k = 0; k < HT; ++k) {
+      const float v = sp[(int64_t)s * HT + k];
+      if (v > mx[k]) { sm[k] = sm[k] * expf(mx[k] - v) + 1.f; mx[k] = v; } else { sm[k] += expf(v - mx[k]); }
     }
-  for (int c = 0; c < HT; ++c) {
-    const float gm = wave_max(mx[c]);
-    const float gs = wave_sum(sm[c] * expf(mx[c] - gm));
+  for (int k = 0; k < HT; ++k) {
+    const float gm = wave_max(mx[k]);
+    const float gs = wave_sum(sm[k] * expf(mx[k] - gm));
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = gm; red[threadIdx.x >> 6][1] = gs; }
     __syncthreads();
@@ -246,29 +248,49 @@ __global__ __launch_bounds__(256) void biattn_colstats_kernel(const float* __res
       const float M = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
       float Ssum = 0.f;
       for (int w = 0; w < 4; ++w) Ssum += red[w][1] * expf(red[w][0] - M);
-      stats[((int64_t)b * HT + c) * 2] = M;
-      stats[((int64_t)b * HT + c) * 2 + 1] = Ssum;
+      part[(((int64_t)b * nchunk + c) * HT + k) * 2] = M;
+      part[(((int64_t)b * nchunk + c) * HT + k) * 2 + 1] = Ssum;
     }
   }
 }
+// pass 1b: combine the chunk partials -> stats[b][col] = (max, sum-exp)
+__global__ __launch_bounds__(64) void biattn_colstats_combine_kernel(const float* __restrict__ part, int nchunk,
+                                                                     int HT, float* __restrict__ stats) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  if (k >= HT) return;
+  float M = -3.0e38f;
+  for (int c = 0; c < nchunk; ++c) M = fmaxf(M, part[(((int64_t)b * nchunk + c) * HT + k) * 2]);
+  float Ssum = 0.f;
+  for (int c = 0; c < nchunk; ++c)
+    Ssum += part[(((int64_t)b * nchunk + c) * HT + k) * 2 + 1] * expf(part[(((int64_t)b * nchunk + c) * HT + k) * 2] - M);
+  stats[((int64_t)b * HT + k) * 2] = M;
+  stats[((int64_t)b * HT + k) * 2 + 1] = Ssum;
+}
 
 // text side, pass 2: partial[b,h,chunk,t,d] = sum_{s in chunk} exp(score[s,h,t]-max) * values_v[s,h,d]
+// (the chunk's exp() values are computed ONCE into LDS, not once per output dim)
 template <int E>
 __global__ __launch_bounds__(256) void biattn_text_partial_kernel(const float* __restrict__ scores,
                                                                   const float* __restrict__ stats,
                                                                   const f16* __restrict__ QV, int S, int T,
                                                                   int chunk, float* __restrict__ partial) {
   constexpr int H = 4, HD = E / H, LD = 2 * E;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* pe = (float*)smem;                                 // [chunk][T]
   const int nchunk = gridDim.x;
   const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int d = threadIdx.x;                                // HD == 256 == blockDim
-  float acc[16], mx[16];
-  for (int t = 0; t < T; ++t) { acc[t] = 0.f; mx[t] = stats[((int64_t)b * H * T + h * T + t) * 2]; }
   const int s0 = c * chunk, s1 = min(S, s0 + chunk);
+  for (int i = threadIdx.x; i < (s1 - s0) * T; i += 256) {
+    const int r = i / T, t = i % T;
+    pe[i] = expf(scores[(((int64_t)b * S + s0 + r) * H + h) * T + t] - stats[((int64_t)b * H * T + h * T + t) * 2]);
+  }
+  __syncthreads();
+  float acc[16];
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
   for (int s = s0; s < s1; ++s) {
     const float v = (float)QV[((int64_t)b * S + s) * LD + E + h * HD + d];
-    const float* sp = scores + (((int64_t)b * S + s) * H + h) * T;
-    for (int t = 0; t < T; ++t) acc[t] = fmaf(expf(sp[t] - mx[t]), v, acc[t]);
+    for (int t = 0; t < T; ++t) acc[t] = fmaf(pe[(s - s0) * T + t], v, acc[t]);
   }
   for (int t = 0; t < T; ++t)
     partial[((((int64_t)b * H + h) * nchunk + c) * T + t) * HD + d] = acc[t];
@@ -592,10 +614,15 @@ extern "C" int ink_biattn_fusion(const void* QV_f16, const void* KL_f16, int32_t
   const int bx = (S + 3) / 4 < 512 ? (S + 3) / 4 : 512;
   hipLaunchKernelGGL(biattn_image_kernel<1024>, dim3(bx, B), dim3(256), lds, s, (const f16*)QV_f16,
                      (const f16*)KL_f16, B, S, T, scale, scores_ws, (f16*)out_v_f16);
-  hipLaunchKernelGGL(biattn_colstats_kernel, dim3(B), dim3(256), 0, s, scores_ws, S, 4 * T, stats_ws);
   const int nchunk = (S + chunk - 1) / chunk;
-  hipLaunchKernelGGL(biattn_text_partial_kernel<1024>, dim3(nchunk, 4, B), dim3(256), 0, s, scores_ws, stats_ws,
-                     (const f16*)QV_f16, S, T, chunk, partial_ws);
+  // column statistics: chunk partials are parked at the head of partial_ws (consumed before pass 2 rewrites it)
+  const int rows_cs = 512, ncs = (S + rows_cs - 1) / rows_cs;
+  INK_CHECK_ARG((int64_t)ncs * 4 * T * 2 <= (int64_t)4 * nchunk * T * 256);
+  hipLaunchKernelGGL(biattn_colstats_partial_kernel, dim3(ncs, B), dim3(256), 0, s, scores_ws, S, 4 * T, rows_cs,
+                     partial_ws);
+  hipLaunchKernelGGL(biattn_colstats_combine_kernel, dim3(B), dim3(64), 0, s, partial_ws, ncs, 4 * T, stats_ws);
+  hipLaunchKernelGGL(biattn_text_partial_kernel<1024>, dim3(nchunk, 4, B), dim3(256), chunk * T * 4, s, scores_ws,
+                     stats_ws, (const f16*)QV_f16, S, T, chunk, partial_ws);
   hipLaunchKernelGGL(biattn_text_reduce_kernel<1024>, dim3(T, 4, B), dim3(256), 0, s, partial_ws, stats_ws, T,
                      nchunk, (f16*)out_l_f16);
   return ink_launch_status();
