@@ -53,37 +53,70 @@ def build_engines(dev, rank, world, batch):
 
 
 def cpu_baseline(n_boxes):
-    """The CPU oracle (oracle/, a port of the reference's PyTorch modules pinned by tests/golden) timed on
-    this box's host cores on ONE sketch of the same workload."""
+    """The CPU oracle (oracle/, a port of the reference's PyTorch modules pinned by tests/golden) timed on this
+    box's host cores on a BOUNDED sample of one sketch of the same workload: GroundingDINO in full; of SAM's
+    32 ViT-H blocks one windowed and one global block are run and the encoder time is extrapolated
+    (28 x windowed + 4 x global + patch-embed + neck); the mask decoder on 4 boxes, scaled to n_boxes."""
     from oracle import gdino_ref, sam_ref
     from inklayer_amd import synthetic, weights_init, sam as psam, gdino as pgd
-    torch.manual_seed(0)
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
     torch.set_num_threads(max(1, ncpu))       # the threads this process may actually run on
-    scfg, gcfg = sam_ref.SamConfig(), gdino_ref.GDinoConfig()
-    ssd = weights_init.random_sam_state_dict(psam.SamConfig(), "cpu", 0)
+    say = lambda m: print(f"[cpu_baseline] {m}", file=sys.stderr, flush=True)
+    scfg = sam_ref.SamConfig(depth=8, global_attn_indexes=(7,))          # blocks 0 (windowed) and 7 (global) are timed
+    gcfg = gdino_ref.GDinoConfig()
+    say(f"{ncpu} threads; generating random weights")
+    ssd = weights_init.random_sam_state_dict(psam.SamConfig(depth=8, global_attn_indexes=(7,)), "cpu", 0)
     gsd = weights_init.random_gdino_state_dict(pgd.GDinoConfig(), "cpu", 1)
     text = weights_init.random_text_features(pgd.GDinoConfig(), "cpu")
     sm, pid = gdino_ref.text_masks_and_position_ids([101, 4874, 1012, 102])
     img = synthetic.synthetic_sketch(0)
-    t0 = time.time()
+    T = {}
     with torch.no_grad():
+        t0 = time.time()
         x = gdino_ref.load_image(img)
         logits, boxes = gdino_ref.detector_forward(gsd, gcfg, x[None], text, sm, pid)
         score = logits[0].sigmoid().max(-1)[0]
-        order = torch.sort(score, descending=True, stable=True)[1][:n_boxes]
+        order = torch.sort(score, descending=True, stable=True)[1][:4]
         b = boxes[0][order].double().numpy()
+        T["detector"] = time.time() - t0
+        say(f"detector {T['detector']:.1f} s")
         xyxy = np.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], -1)
         pix = torch.tensor(xyxy * 1024.0).float()
-        masks = sam_ref.run_sam(ssd, scfg, img, pix)
-    dt = time.time() - t0
-    assert len(masks) == n_boxes
-    return {"value": 1.0 / dt, "unit": "sketches/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 synthetic 1024x1024 sketch, full GroundingDINO Swin-T + SAM ViT-H, {n_boxes} boxes, "
-                      f"fp32 torch CPU oracle, {dt:.1f} s"}
+        t0 = time.time()
+        xin = sam_ref.preprocess(scfg, torch.from_numpy(img[..., ::-1].copy()).permute(2, 0, 1))[None]
+        tok = sam_ref.image_encoder(ssd, scfg, xin, upto=0)
+        T["patch_embed"] = time.time() - t0
+        t0 = time.time()
+        tok = sam_ref.vit_block(ssd, scfg, 0, tok)
+        T["win_block"] = time.time() - t0
+        t0 = time.time()
+        tok = sam_ref.vit_block(ssd, scfg, 7, tok)
+        T["glob_block"] = time.time() - t0
+        say(f"ViT-H blocks: windowed {T['win_block']:.2f} s, global {T['glob_block']:.2f} s")
+        t0 = time.time()
+        import torch.nn.functional as F
+        e = tok.permute(0, 3, 1, 2)
+        e = F.conv2d(e, ssd["image_encoder.neck.0.weight"])
+        e = sam_ref._ln2d(e, ssd["image_encoder.neck.1.weight"], ssd["image_encoder.neck.1.bias"])
+        e = F.conv2d(e, ssd["image_encoder.neck.2.weight"], padding=1)
+        emb = sam_ref._ln2d(e, ssd["image_encoder.neck.3.weight"], ssd["image_encoder.neck.3.bias"])
+        T["neck"] = time.time() - t0
+        t0 = time.time()
+        low, _ = sam_ref.mask_decoder(ssd, scfg, emb, sam_ref.dense_pe(ssd, scfg), sam_ref.embed_boxes(ssd, scfg, pix))
+        masks = sam_ref.postprocess_masks(scfg, low, (1024, 1024), (1024, 1024)) > 0
+        T["decoder4"] = time.time() - t0
+    total = (T["detector"] + T["patch_embed"] + 28 * T["win_block"] + 4 * T["glob_block"] + T["neck"]
+             + T["decoder4"] * n_boxes / 4.0)
+    work = sum(T.values())
+    say(f"measured {work:.1f} s of CPU work -> {total:.1f} s per sketch extrapolated")
+    return {"value": 1.0 / total, "unit": "sketches/s", "cores": ncpu, "kind": "port",
+            "sample": f"1 synthetic 1024x1024 sketch: GroundingDINO Swin-T in full ({T['detector']:.1f} s); SAM ViT-H "
+                      f"patch-embed + 1 windowed block ({T['win_block']:.2f} s) + 1 global block ({T['glob_block']:.2f} s) "
+                      f"+ neck, encoder extrapolated as 28 x windowed + 4 x global; mask decoder + postprocess on 4 boxes "
+                      f"scaled to {n_boxes}; fp32 torch CPU oracle, {work:.1f} s measured -> {total:.1f} s per sketch"}
 
 
 def main():
@@ -126,8 +159,13 @@ def main():
     assert len(res) == B and res[0].masks.shape == (args.boxes, 1024, 1024)
 
     if rank == 0:
+        traffic = None
+        pmc = ROOT / "profiles" / "r01_gemm_pmc.json"
+        if pmc.exists():      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+            traffic = json.loads(pmc.read_text()).get("traffic_bytes_per_launch")
         gemm_ms = sum(t[1].elapsed_time(t[2]) for t in trace)
         gemm_flops = sum(t[0] for t in trace)
+        gemm_bytes = sum(2.0 * (t[3][0] * t[3][2] + t[3][1] * t[3][2]) + t[3][0] * t[3][1] * ((2 if t[3][6] == 'f16' else 4) + (4 if t[3][4] == 'res' else 0)) for t in trace)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         sketches = B * world * args.steps
         out = {
@@ -140,9 +178,11 @@ def main():
                                    "1024x1024 synthetic sketches, 16 boxes/sketch, random-init weights",
                        "global_batch": B * world, "boxes_per_sketch": args.boxes,
                        "parallelism": f"image-parallel x{world}", "weight_broadcast_s": round(bcast_s, 3)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16_nt_128 (all dense projections)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16_nt<256,256,64,4,4,2> + small-tile variants (all dense projections)",
                          "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F16_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM-side bytes per launch of the 256x256 tile kernel (2*FETCH_SIZE + WRITE_SIZE)",
+                         "algorithmic_bytes_per_launch": gemm_bytes / max(1, len(trace)),
                          "launches_per_step": len(trace) // max(1, args.steps),
                          "gemm_ms_per_step": gemm_ms / max(1, args.steps),
                          "gemm_tflop_per_sketch": gemm_flops / max(1, args.steps) / B / 1e12,
