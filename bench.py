@@ -52,6 +52,23 @@ def build_engines(dev, rank, world, batch):
     return det, seg, bcast_s
 
 
+def _cpu_share() -> int:
+    """Host cores this process can really use: min(affinity, cgroup cpu.max quota, 16).  The GPU box exposes
+    all of the host's hardware threads to sched_getaffinity but gives one-GPU jobs a ~16-CPU share; running
+    torch with hundreds of threads on that share oversubscribes it by 10x and never finishes."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(n_boxes):
     """The CPU oracle (oracle/, a port of the reference's PyTorch modules pinned by tests/golden) timed on this
     box's host cores on a BOUNDED sample of one sketch of the same workload: GroundingDINO in full; of SAM's
@@ -59,11 +76,8 @@ def cpu_baseline(n_boxes):
     (28 x windowed + 4 x global + patch-embed + neck); the mask decoder on 4 boxes, scaled to n_boxes."""
     from oracle import gdino_ref, sam_ref
     from inklayer_amd import synthetic, weights_init, sam as psam, gdino as pgd
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, ncpu))       # the threads this process may actually run on
+    ncpu = _cpu_share()
+    torch.set_num_threads(ncpu)
     say = lambda m: print(f"[cpu_baseline] {m}", file=sys.stderr, flush=True)
     scfg = sam_ref.SamConfig(depth=8, global_attn_indexes=(7,))          # blocks 0 (windowed) and 7 (global) are timed
     gcfg = gdino_ref.GDinoConfig()
