@@ -63,6 +63,9 @@ int ink_gemm_f16(const InkGemm* p, void* stream);
  * -1 restores the built-in shape heuristic.  Results are identical across variants up to f32
  * summation order. */
 int ink_gemm_set_variant(int32_t v);
+/* Which tile variant the built-in heuristic picks for (M,N,K): 10 = 256x256x64 / 16 waves (the dominant kernel),
+ * 0 = 128x128x64 / 4 waves, 32 = 128x128x32 (K % 64 != 0).  Pure host function, used by bench.py's roofline. */
+int ink_gemm_query_variant(int32_t M, int32_t N, int32_t K);
 
 /* ------------------------------------------------------------------------
  * Row LayerNorm with optional row gather (fuses window-partition / pad /

@@ -42,6 +42,7 @@ SIGNATURES = {
     "ink_abi_version": [],
     "ink_gemm_f16": [C.POINTER(InkGemm), c_void_p],
     "ink_gemm_set_variant": [c_int],
+    "ink_gemm_query_variant": [c_int, c_int, c_int],
     "ink_layernorm_rows": [c_void_p, c_i64, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                            c_void_p, c_void_p, c_i64, c_int, c_void_p],
     "ink_add_cvt_f16": [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p],

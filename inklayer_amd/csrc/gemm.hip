@@ -210,6 +210,14 @@ static int launch_gemm(const InkGemm& p, hipStream_t s, int group_m = 1) {
 }  // namespace
 
 static int g_variant = -1;
+// shape heuristic (tools/gemm_sweep.py on MI355X): the 16-wave 256x256 tile wins whenever it fills the chip
+// (>= ~200 tiles) and N does not waste a large part of a 256-wide tile; else the 128x128 tile.
+extern "C" int ink_gemm_query_variant(int32_t M, int32_t N, int32_t K) {
+  if (K % 64 != 0) return 32;      // 128x128x32 tile
+  const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  const bool n_fits = (N % 256 == 0) || N >= 1024;
+  return (tiles256 >= 200 && n_fits) ? 10 : 0;
+}
 extern "C" int ink_abi_version(void) { return INK_ABI_VERSION; }
 extern "C" int ink_gemm_set_variant(int32_t v) {
   g_variant = v;
@@ -235,11 +243,7 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
   if (v >= 100) { gm = v / 100; v = v % 100; }
   if (p.K % 64 != 0) return launch_gemm<128, 128, 32, 2, 2, 2>(p, s);
   if (v < 0) {
-    // shape heuristic (tools/gemm_sweep.py on MI355X): the 16-wave 256x256 tile wins whenever it fills the
-    // chip (>= ~200 tiles) and N does not waste a large part of a 256-wide tile; else the 128x128 tile.
-    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    const bool n_fits = (p.N % 256 == 0) || p.N >= 1024;
-    v = (tiles256 >= 200 && n_fits) ? 10 : 0;
+    v = ink_gemm_query_variant(p.M, p.N, p.K);
     gm = 4;
   }
   switch (v) {

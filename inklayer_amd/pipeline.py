@@ -72,7 +72,11 @@ class InkLayerPipeline:
         return det_in, sam_in, sizes
 
     @torch.no_grad()
-    def run_prepared(self, det_in, sam_in, sizes, top_n: Optional[int] = None) -> List[SketchResult]:
+    def run_prepared(self, det_in, sam_in, sizes, top_n: Optional[int] = None,
+                     defer_sync: bool = False) -> List[SketchResult]:
+        """defer_sync=True (needs overlap): the caller's stream is NOT made to wait for the results; consecutive
+        batches then pipeline (batch i+1's detector runs under batch i's encoder/decoder).  The caller must call
+        `synchronize()` (or wait on `s_seg`) before touching the returned masks."""
         if self.overlap:
             cur = torch.cuda.current_stream(self.dev)
             self.s_det.wait_stream(cur)
@@ -95,13 +99,20 @@ class InkLayerPipeline:
             stream_ctx = _NullCtx()
         with stream_ctx:
             out = self._decode_all(dets, emb, sizes)
-        if self.overlap:
+        if self.overlap and not defer_sync:
             cur = torch.cuda.current_stream(self.dev)
             cur.wait_stream(self.s_seg)
             cur.wait_stream(self.s_det)
             for r in out:                                  # results are consumed on the caller's stream
                 r.masks.record_stream(cur)
         return out
+
+    def synchronize(self) -> None:
+        """Join both pipeline streams into the caller's stream (after a run of defer_sync=True batches)."""
+        if self.overlap:
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_stream(self.s_seg)
+            cur.wait_stream(self.s_det)
 
     def _decode_all(self, dets, emb, sizes) -> List[SketchResult]:
         L = self.seg.cfg.img_size

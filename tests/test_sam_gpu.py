@@ -158,3 +158,12 @@ def test_pipeline_two_stream_overlap_equals_serial(dev, small_vith):
     for ra, rb in zip(a, b):
         assert np.array_equal(ra.boxes_xyxy_norm, rb.boxes_xyxy_norm) and torch.equal(ra.masks, rb.masks)
         assert ra.masks.shape == (5, 600, 800) and ra.masks.dtype == torch.uint8
+    # pipelined batches (deferred stream join) give the same masks again
+    pp = pipeline.InkLayerPipeline(det, eng, overlap=True)
+    d_in, s_in, sz = pp.prepare(imgs)
+    outs = [pp.run_prepared(d_in, s_in, sz, top_n=5, defer_sync=True) for _ in range(3)]
+    pp.synchronize()
+    torch.cuda.synchronize()
+    for o in outs:
+        for ro, rb in zip(o, b):
+            assert torch.equal(ro.masks, rb.masks)
