@@ -165,32 +165,92 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
   }
 
   // ---- epilogue: lane holds C[m = .. + fr][n = .. + 4*fq + 0..3] for each (i,j)
+  if (ABL == 3) {   // ablation: no epilogue (keep the accumulators live)
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 123.456f) ((float*)p.C)[0] = sum;
+    return;
+  }
+  // Each 16-row slab of the wave's tile goes through a wave-private LDS patch so that HBM sees whole row
+  // segments (16 B per lane, 128 B (f16) / 256 B (f32) contiguous per row) instead of 8/16-B fragments; the
+  // residual is read the same way.  bias / activation / layer-scale are applied on the way in (the lane holds 4
+  // consecutive columns), residual + store on the way out.
+  constexpr int WNC = BN / WN;                 // columns of the wave tile
+  constexpr int EP = WNC * 4 + 16;             // patch row pitch in bytes (f32 worst case + pad)
+  static_assert(WM * WN * 16 * EP <= NS * STAGE, "epilogue patch must fit in the staging LDS");
+  __syncthreads();                             // every wave is done reading the last K-tile
+  char* er = smem + wave * (16 * EP);
+  const bool f16o = p.c_f16 != 0;
+  const bool wide16 = f16o && (p.ldc % 8 == 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * (BM / WM) + i * 16 + fr;
-    if (m >= p.M) continue;
-    const int orow = p.row_map ? p.row_map[m] : m;
-    if (orow < 0) continue;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
-      if (n >= p.N) continue;
+      const int n = n0 + wn * WNC + j * 16 + fq * 4;
       f32x4 v = acc[i][j];
-      if (p.bias) v += *(const f32x4*)(p.bias + n);
-      if (p.act == INK_ACT_GELU) {
+      if (n < p.N) {
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if (p.act == INK_ACT_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-      } else if (p.act == INK_ACT_RELU) {
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        } else if (p.act == INK_ACT_RELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.col_scale) v *= *(const f32x4*)(p.col_scale + n);
       }
-      if (p.col_scale) v *= *(const f32x4*)(p.col_scale + n);
-      if (p.residual) v += *(const f32x4*)(p.residual + (size_t)orow * p.ldr + n);
-      if (p.c_f16) {
-        f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-        *(f16x4*)((f16*)p.C + (size_t)orow * p.ldc + n) = h;
+      if (f16o) {
+        *(f16x4*)(er + fr * EP + (j * 16 + fq * 4) * 2) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
       } else {
-        *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + n) = v;
+        *(f32x4*)(er + fr * EP + (j * 16 + fq * 4) * 4) = v;
+      }
+    }
+    const int mbase = m0 + wm * (BM / WM) + i * 16;
+    if (f16o) {
+      constexpr int CPRW = WNC * 2 / 16;       // 16-B chunks per patch row
+#pragma unroll
+      for (int it = 0; it < (16 * CPRW + 63) / 64; ++it) {
+        const int c = it * 64 + lane;
+        const int row = c / CPRW, cc = c % CPRW;
+        const int m = mbase + row, n = n0 + wn * WNC + cc * 8;
+        if (c < 16 * CPRW && m < p.M && n < p.N) {
+          const int orow = p.row_map ? p.row_map[m] : m;
+          if (orow >= 0) {
+            f16x8 d = *(const f16x8*)(er + row * EP + cc * 16);
+            f16* dst = (f16*)p.C + (size_t)orow * p.ldc + n;
+            if (p.residual) {
+              const float* rp = p.residual + (size_t)orow * p.ldr + n;
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (n + e < p.N) d[e] = (f16)((float)d[e] + rp[e]);
+            }
+            if (wide16 && n + 8 <= p.N) {
+              *(f16x8*)dst = d;
+            } else {
+              *(f16x4*)dst = (f16x4){d[0], d[1], d[2], d[3]};
+              if (n + 8 <= p.N) *(f16x4*)(dst + 4) = (f16x4){d[4], d[5], d[6], d[7]};
+            }
+          }
+        }
+      }
+    } else {
+      constexpr int CPRW = WNC * 4 / 16;
+#pragma unroll
+      for (int it = 0; it < (16 * CPRW + 63) / 64; ++it) {
+        const int c = it * 64 + lane;
+        const int row = c / CPRW, cc = c % CPRW;
+        const int m = mbase + row, n = n0 + wn * WNC + cc * 4;
+        if (c < 16 * CPRW && m < p.M && n < p.N) {
+          const int orow = p.row_map ? p.row_map[m] : m;
+          if (orow >= 0) {
+            f32x4 d = *(const f32x4*)(er + row * EP + cc * 16);
+            if (p.residual) d += *(const f32x4*)(p.residual + (size_t)orow * p.ldr + n);
+            *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + n) = d;
+          }
+        }
       }
     }
   }
@@ -259,6 +319,7 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s, gm);    // 16 waves x (64x64)
     case 21: return launch_gemm<256, 256, 64, 4, 4, 2, 1>(p, s, gm);  // ablation: no DMA after tile 1
     case 22: return launch_gemm<256, 256, 64, 4, 4, 2, 2>(p, s, gm);  // ablation: no MFMA
+    case 23: return launch_gemm<256, 256, 64, 4, 4, 2, 3>(p, s, gm);  // ablation: no epilogue
     case 11: return launch_gemm<256, 256, 32, 4, 4, 4>(p, s);    // 16 waves, 3 half-tiles in flight
     case 14: return launch_gemm<256, 128, 32, 4, 2, 2>(p, s, gm);    // 48 KB: 2-3 blocks/CU, 8 waves x (64x64)
     case 15: return launch_gemm<128, 256, 32, 2, 4, 2>(p, s, gm);
