@@ -96,14 +96,17 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
         for (int r = 0; r < 4; ++r) bias3[sub][4 * g + r] = v[r];
       }
   }
+  f32x16 rw0, rw1;      // mode 1: rel_w[q, kw] of this lane's query for the 2 x 16 key slots of a tile; they are
+                        // the C operand of the first QK^T MFMA of every tile (C != D: no copies, no LDS, no VALU)
   if constexpr (MODE == 1) {
-    // rel_w[q, kw] of this lane's query -> LDS, float4 i of lane t at ((i*NT + t)*16): every tile re-reads it
-    // straight into the S accumulators (LDS pipe, no VALU, no registers held across the loop)
     const float* RW = p.rel_w + ((int64_t)bh * p.n_q + q_c) * 64;
     RH = p.rel_h + ((int64_t)bh * p.n_q + q_c) * 64;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      *(f32x4*)(sR + (i * NT + tid) * 16) = *(const f32x4*)(RW + (i >> 2) * 32 + 8 * (i & 3) + 4 * hh);
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 a = *(const f32x4*)(RW + 8 * g + 4 * hh), c2 = *(const f32x4*)(RW + 32 + 8 * g + 4 * hh);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { rw0[4 * g + r] = a[r]; rw1[4 * g + r] = c2[r]; }
+    }
   }
 
   // V pad columns: zero, except a ones-column (d = HD for the lower half-wave, HD+4 for the upper) so that the
@@ -251,13 +254,10 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
 
     f32x16 s0, s1;
     if constexpr (MODE == 1) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 a = *(const f32x4*)(sR + (g * NT + tid) * 16);
-        const f32x4 bq = *(const f32x4*)(sR + ((4 + g) * NT + tid) * 16);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s0[4 * g + r] = a[r]; s1[4 * g + r] = bq[r]; }
-      }
+      const f16x8 k0 = *(const f16x8*)(tK + koff0);
+      const f16x8 k1 = *(const f16x8*)(tK + koff1);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[0], rw0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[0], rw1, 0, 0, 0);
     } else if constexpr (MODE == 3) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
       for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
     }
 #pragma unroll
-    for (int s = 0; s < NQK; ++s) {
+    for (int s = (MODE == 1 ? 1 : 0); s < NQK; ++s) {
       const f16x8 k0 = *(const f16x8*)(tK + koff0 + s * 32);
       const f16x8 k1 = *(const f16x8*)(tK + koff1 + s * 32);
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
@@ -543,7 +543,7 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
   {                                                                                                        \
     constexpr int nqk_ = HD / 16 + (MODE == 2 ? 2 : 0);                                                    \
     constexpr int lds_ = (ALL ? 4 : 1) * (64 * (((nqk_ * 2) | 1) * 16) + 64 * (((HD + 31) / 32) * 64)) +   \
-                         (MODE == 1 ? NW * 64 * 128 : 0);                                               \
+                         0;                                                                            \
     static bool attr_ = ((void)hipFuncSetAttribute((const void*)flash_attn_kernel<HD, MODE, NW, ALL>,      \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_), true); \
     (void)attr_;                                                                                           \

@@ -27,10 +27,15 @@ def init_process_group(backend: str | None = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # INK_DIST_BACKEND=gloo: rehearsal hook (several ranks sharing one GPU, where RCCL refuses duplicates)
+            backend = os.environ.get("INK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
+        if "INK_FORCE_DEVICE" in os.environ:        # rehearsal hook: every rank on the same card
+            local = int(os.environ["INK_FORCE_DEVICE"])
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif "INK_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["INK_FORCE_DEVICE"])
     return rank, world, local
 
 

@@ -65,9 +65,9 @@ class InkLayerPipeline:
         det_in, sam_in, sizes = [], [], []
         L = self.seg.cfg.img_size
         for im in images_rgb:
-            det_in.append(torch.from_numpy(gd.resize_for_detector(im)).to(self.dev, non_blocking=True))
+            det_in.append(torch.from_numpy(np.array(gd.resize_for_detector(im))).to(self.dev, non_blocking=True))
             rs = sm.resize_longest_side(np.ascontiguousarray(im[..., ::-1]), L)   # sam.py:24-26 channel reversal
-            sam_in.append(torch.from_numpy(np.ascontiguousarray(rs)).to(self.dev, non_blocking=True))
+            sam_in.append(torch.from_numpy(np.array(rs)).to(self.dev, non_blocking=True))
             sizes.append(((im.shape[0], im.shape[1]), tuple(rs.shape[:2])))
         return det_in, sam_in, sizes
 

@@ -7,7 +7,7 @@ import bench
 from inklayer_amd import ops, pipeline, synthetic
 dev = torch.device("cuda:0")
 det, seg, _ = bench.build_engines(dev, 0, 1, 8)
-pipe = pipeline.InkLayerPipeline(det, seg)
+pipe = pipeline.InkLayerPipeline(det, seg, overlap=False)
 imgs = [synthetic.synthetic_sketch(i) for i in range(8)]
 d, s, z = pipe.prepare(imgs)
 pipe.run_prepared(d, s, z, top_n=16)
