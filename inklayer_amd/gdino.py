@@ -520,10 +520,23 @@ class GDinoEngine:
 
     # ------------------------------------------------------------------ whole model
     def forward(self, images_u8: Sequence[torch.Tensor], stages: Optional[dict] = None):
-        """images_u8: resized HWC uint8 CUDA tensors of ONE common size.  -> (logits, boxes) on the GPU."""
+        """images_u8: resized HWC uint8 CUDA tensors.  -> (logits [B,nq,T], boxes [B,nq,4]) on the GPU.
+        Images of different sizes are run as separate equal-size groups (the reference pads a NestedTensor
+        instead; it only ever sees one image per call, GD/util/inference.py:67)."""
         B = len(images_u8)
-        h, w_ = images_u8[0].shape[:2]
-        assert all(tuple(im.shape[:2]) == (h, w_) for im in images_u8), "batch must share one size"
+        sizes = [tuple(im.shape[:2]) for im in images_u8]
+        if len(set(sizes)) > 1:
+            assert stages is None
+            logits = torch.empty((B, self.cfg.num_queries, self.T), device=self.dev, dtype=F32)
+            boxes = torch.empty((B, self.cfg.num_queries, 4), device=self.dev, dtype=F32)
+            for sz in dict.fromkeys(sizes):
+                idx = [i for i, s_ in enumerate(sizes) if s_ == sz]
+                lg, bx = self.forward([images_u8[i] for i in idx])
+                ii = torch.tensor(idx, device=self.dev)
+                logits[ii] = lg
+                boxes[ii] = bx
+            return logits, boxes
+        h, w_ = sizes[0]
         pl = self.plan(h, w_, B)
         feats = self.backbone(images_u8, pl)
         src = self.neck(feats, pl, B)

@@ -167,3 +167,26 @@ def test_pipeline_two_stream_overlap_equals_serial(dev, small_vith):
     for o in outs:
         for ro, rb in zip(o, b):
             assert torch.equal(ro.masks, rb.masks)
+
+
+@torch.no_grad()
+def test_pipeline_mixed_sizes_and_empty_detections(dev, small_vith):
+    """A batch of differently sized sketches (detector runs per size group) and the zero-box edge case."""
+    from inklayer_amd import gdino, pipeline, weights_init
+    sd, oc, eng = small_vith
+    gcfg = gdino.GDinoConfig(enc_layers=1, dec_layers=1, num_queries=100)
+    det = gdino.GDinoEngine(weights_init.random_gdino_state_dict(gcfg, dev, 5), gcfg, dev,
+                            encoded_text=weights_init.random_text_features(gcfg, dev))
+    pipe = pipeline.InkLayerPipeline(det, eng)
+    imgs = [_sketch(1, 512, 512), _sketch(2, 600, 800)]
+    both = pipe.run_batch(imgs, top_n=3)
+    solo = [pipe.run_batch([im], top_n=3)[0] for im in imgs]
+    torch.cuda.synchronize()
+    for r, s_, im in zip(both, solo, imgs):
+        assert r.masks.shape == (3,) + im.shape[:2]
+        assert np.allclose(r.boxes_xyxy_norm, s_.boxes_xyxy_norm, atol=1e-5) and torch.equal(r.masks, s_.masks)
+    # threshold so high that nothing is detected -> empty results, no kernel is launched for the decoder
+    det.cfg.box_threshold = 2.0
+    res = pipe.run_batch(imgs)
+    assert all(r.masks.shape[0] == 0 and r.boxes_xyxy_norm.shape == (0, 4) for r in res)
+    det.cfg.box_threshold = 0.2
