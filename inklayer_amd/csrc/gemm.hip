@@ -32,6 +32,141 @@ template <> struct Swz<32> {  // 64-B rows, 4 chunks
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// ---------------------------------------------------------------------------------------------------------
+// Accumulator set-up and epilogue of one wave tile (TM x TN MFMA tiles of 16x16; the lane holds
+// C[m = mw + 16*ti + fr][n = nw + 16*j + 4*fq + 0..3]), shared by every kernel in this file.
+//
+// Loads and stores share vmcnt and retire in issue order in the counter, so a load issued AFTER a store can only
+// be waited for with vmcnt(0) - i.e. by waiting for that store to reach memory (and the compiler has to assume
+// the worst over all paths, so "counted" waits degrade to 0 as soon as a store may be skipped).  Measured with
+// s_memrealtime stamps (tools/gemm_stamps.py): with the row_map / residual / bias loads inside the slab loop each
+// of the 8 slabs of a 256x256 tile paid a full store round trip, 7.5 us per tile against a 31 us main loop.
+// So the slab loop contains NO load:
+//   * the residual of the linear case (no activation, no layer scale - every large GEMM of the pipeline) is
+//     loaded straight into the accumulators before the K loop, row-mapped, and the MFMAs accumulate on top of it
+//     (the four j-loads of a row cover 256 contiguous bytes; they overlap the pipeline fill);
+//   * bias and the output row of every store chunk are loaded before the first store;
+//   * the rare non-linear residual / layer-scale loads stay in the loop, each used inside its own branch.
+__device__ __forceinline__ bool residual_preloaded(const InkGemm& p) {
+  return p.residual && p.act == INK_ACT_NONE && !p.col_scale;
+}
+
+// residual rows of the accumulator layout (-1: nothing to preload); issued BEFORE the first K-tile DMA so that the
+// wait for them is a counted one, the residual loads themselves go out behind the DMA (init_wave_tile)
+template <int TM>
+__device__ __forceinline__ void residual_rows(int (&rr)[TM], const InkGemm& p, int mw, int lane) {
+  const bool pre = residual_preloaded(p);
+#pragma unroll
+  for (int ti = 0; ti < TM; ++ti) {
+    const int m = mw + ti * 16 + (lane & 15);
+    int r = -1;
+    if (pre && m < p.M) r = p.row_map ? p.row_map[m] : m;
+    rr[ti] = r;
+  }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void init_wave_tile(f32x4 (&acc)[TM][TN], const InkGemm& p, const int (&rr)[TM], int nw,
+                                               int lane) {
+  const int fq = lane >> 4;
+#pragma unroll
+  for (int ti = 0; ti < TM; ++ti) {
+    const float* rp = p.residual + (size_t)max(rr[ti], 0) * p.ldr + nw + fq * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      acc[ti][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (rr[ti] >= 0 && nw + j * 16 + fq * 4 < p.N) acc[ti][j] = *(const f32x4*)(rp + j * 16);
+    }
+  }
+}
+
+// Each 16-row slab goes through a wave-private LDS patch so that HBM sees whole row segments (16 B per lane,
+// 128 B (f16) / 256 B (f32) contiguous per row); bias / activation / layer-scale are applied on the way in.
+template <int TM, int TN, bool F16O>
+__device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkGemm& p, char* er, int mw, int nw,
+                                                int lane) {
+  constexpr int WNC = TN * 16, EP = WNC * 4 + 16;
+  constexpr int ES = F16O ? 8 : 4;                 // elements per 16-B chunk of the output row
+  constexpr int CPRW = WNC / ES;                   // chunks per patch row (divides 64)
+  constexpr int NIT = (16 * CPRW + 63) / 64;       // chunk rounds per slab
+  constexpr int RPI = 64 / CPRW;                   // patch rows per round
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool wide16 = F16O && (p.ldc % 8 == 0);
+  const bool res_late = p.residual && !residual_preloaded(p);
+  const int c_row = lane / CPRW, c_n = nw + (lane % CPRW) * ES;    // the lane's chunk column is the same every round
+
+  // every load up front: output rows of the store chunks (-1 = nothing to store), bias
+  int orow[TM][NIT];
+#pragma unroll
+  for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + c_row;
+      const int m = mw + ti * 16 + row;
+      int r = -1;
+      if (row < 16 && m < p.M && c_n < p.N) r = p.row_map ? p.row_map[m] : m;
+      orow[ti][it] = r;
+    }
+  f32x4 bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 16 + fq * 4;
+    bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) bv[j] = *(const f32x4*)(p.bias + n);
+  }
+
+#pragma unroll
+  for (int ti = 0; ti < TM; ++ti) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f32x4 v = acc[ti][j] + bv[j];
+      if (p.act == INK_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      } else if (p.act == INK_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (p.col_scale) {
+        const int n = nw + j * 16 + fq * 4;
+        if (n < p.N) v *= *(const f32x4*)(p.col_scale + n);
+      }
+      if (F16O) {
+        *(f16x4*)(er + fr * EP + (j * 16 + fq * 4) * 2) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+      } else {
+        *(f32x4*)(er + fr * EP + (j * 16 + fq * 4) * 4) = v;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int r = orow[ti][it];
+      if (r >= 0) {
+        const char* src = er + (it * RPI + c_row) * EP + (c_n - nw) * (F16O ? 2 : 4);
+        if (F16O) {
+          f16x8 d = *(const f16x8*)src;
+          f16* dst = (f16*)p.C + (size_t)r * p.ldc + c_n;
+          if (res_late) {
+            const float* rp = p.residual + (size_t)r * p.ldr + c_n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (c_n + e < p.N) d[e] = (f16)((float)d[e] + rp[e]);
+          }
+          if (wide16 && c_n + 8 <= p.N) {
+            *(f16x8*)dst = d;
+          } else {
+            *(f16x4*)dst = (f16x4){d[0], d[1], d[2], d[3]};
+            if (c_n + 8 <= p.N) *(f16x4*)(dst + 4) = (f16x4){d[4], d[5], d[6], d[7]};
+          }
+        } else {
+          f32x4 d = *(const f32x4*)src;
+          if (res_late) d += *(const f32x4*)(p.residual + (size_t)r * p.ldr + c_n);
+          *(f32x4*)((float*)p.C + (size_t)r * p.ldc + c_n) = d;
+        }
+      }
+    }
+  }
+}
+
 // Generic tile: BM x BN output per workgroup, WM x WN waves (each (BM/WM) x (BN/WN)), K step BK,
 // NS LDS stages.  NS == 2: one K-tile in flight, plain __syncthreads (drains the DMA).
 // NS >= 3: NS-1 K-tiles in flight behind a COUNTED s_waitcnt vmcnt(N) + raw s_barrier
@@ -105,11 +240,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
       __builtin_amdgcn_global_load_lds((gptr_t)(srcW[it] + kt * BK), (lptr_t)(base + TILE_A + (it * NT + wave * 64) * 16), 16, 0, 0);
   };
 
+  int rr[TM];
+  residual_rows<TM>(rr, p, m0 + wm * (BM / WM), lane);
   f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
   const int offA = (wm * (BM / WM) + fr) * ROWB;
@@ -138,7 +271,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
 
   if constexpr (NS == 2) {
     stage(0, 0);
+    init_wave_tile<TM, TN>(acc, p, rr, n0 + wn * (BN / WN), lane);
     for (int kt = 0; kt < nk; ++kt) {
+      // the LDS-DMA of tile kt is tracked by vmcnt only: drain it EXPLICITLY before the barrier (whether
+      // __syncthreads() alone emits the vmcnt wait depends on what else the compiler sees in flight)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (kt + 1 < nk && (ABL != 1 || kt == 0)) stage((kt + 1) & 1, kt + 1);
       if (ABL != 2 || kt + 1 == nk) compute(kt & 1);
@@ -147,6 +284,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
       if (s < nk) stage(s, s);
+    init_wave_tile<TM, TN>(acc, p, rr, n0 + wn * (BN / WN), lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the counted waits below assume only DMA in flight)
     int cur = 0, nxt = NS - 1;
     for (int kt = 0; kt < nk; ++kt) {
       // tiles issued after kt and still wanted in flight: min(NS-2, nk-1-kt)
@@ -174,86 +313,198 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
     if (sum == 123.456f) ((float*)p.C)[0] = sum;
     return;
   }
-  // Each 16-row slab of the wave's tile goes through a wave-private LDS patch so that HBM sees whole row
-  // segments (16 B per lane, 128 B (f16) / 256 B (f32) contiguous per row) instead of 8/16-B fragments; the
-  // residual is read the same way.  bias / activation / layer-scale are applied on the way in (the lane holds 4
-  // consecutive columns), residual + store on the way out.
   constexpr int WNC = BN / WN;                 // columns of the wave tile
   constexpr int EP = WNC * 4 + 16;             // patch row pitch in bytes (f32 worst case + pad)
   static_assert(WM * WN * 16 * EP <= NS * STAGE, "epilogue patch must fit in the staging LDS");
   __syncthreads();                             // every wave is done reading the last K-tile
   char* er = smem + wave * (16 * EP);
-  const bool f16o = p.c_f16 != 0;
-  const bool wide16 = f16o && (p.ldc % 8 == 0);
+  if (p.c_f16) {
+    store_wave_tile<TM, TN, true>(acc, p, er, m0 + wm * (BM / WM), n0 + wn * WNC, lane);
+  } else {
+    store_wave_tile<TM, TN, false>(acc, p, er, m0 + wm * (BM / WM), n0 + wn * WNC, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ping-pong kernel: 256x256 tile, 8 waves = two groups of 4 (group = wave / 4 owns 128 rows; one wave of each
+// group per SIMD), K streamed as a ring of RING granules of 32 (32 KiB each: A 256x32 + W 256x32 f16).
+// The groups run the same program staggered by ONE barrier, so in every slot one group issues its 32 MFMAs
+// while the other reads its 12 fragments from LDS and issues the LDS-DMA of the granule RING-1 ahead:
+//     slot      2g          2g+1        2g+2
+//     group 0   LOAD(g)     MFMA(g)     LOAD(g+1)
+//     group 1   MFMA(g-1)   LOAD(g)     MFMA(g)
+// Granule g sits in ring slot g % RING; both groups have read it by the end of slot 2g+1, and the DMA that
+// overwrites it (granule g+RING) is issued in slots 2g+2 / 2g+3.  Every wave ends its LOAD slot with a COUNTED
+// vmcnt (RING-2 granules stay in flight) and every slot ends with a raw s_barrier, so a granule is only read after
+// the wait + barrier that retire it (cdna_hip_programming.md §5 "Read a staged buffer one phase AFTER the wait").
+// 8 waves x <=256 VGPRs leave room for the load-free epilogue (store_wave_tile), which the 16-wave tiles lack.
+//
+// ABL (ablation / instrumentation builds, reachable through ink_gemm_set_variant only): 1 no MFMA, 2 no LDS
+// reads / barriers, 4 every tile reads tile (0,0) (all L2 hits), 8 every workgroup writes (HW_ID, XCC_ID,
+// t_entry, t_filled, t_loop_end, t_stores_issued) in 100 MHz ticks through p.residual (tools/gemm_stamps.py).
+template <int RING, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
+  constexpr int BM = 256, BN = 256, BK = 32, NT = 512;
+  constexpr int CPR = BK / 8, ROWB = BK * 2;
+  constexpr int TILE_A = BM * ROWB, TILE_W = BN * ROWB, GRAN = TILE_A + TILE_W;   // 32 KiB
+  constexpr int IT_A = (BM * CPR) / NT, IT_W = (BN * CPR) / NT;                    // 2 + 2 DMA per thread
+  constexpr int LOADS = IT_A + IT_W;
+  constexpr int TM = 8, TN = 4, WNC = 64;
+  constexpr int EP = WNC * 4 + 16;
+  static_assert(8 * 16 * EP <= RING * GRAN, "patch fits");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;         // grp = wave row (128 rows each), wn = wave column (64 cols)
+  const int fr = lane & 15, fq = lane >> 4;
+
+  unsigned wg_rt[4] = {0, 0, 0, 0};
+  auto stamp_rt = [&](int k) {
+    if ((ABL & 8) && wave == 0) wg_rt[k] = (unsigned)__builtin_amdgcn_s_memrealtime();
+  };
+  stamp_rt(0);
+  const float* dbg_out = p.residual;
+  if (ABL & 8) p.residual = nullptr;
+
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int id = xcd_remap(blockIdx.x, ntm * ntn);
+  int mt, nt;
+  if (group_m > 1) {
+    const int per = group_m * ntn;
+    const int first = (id / per) * group_m;
+    const int gsz = min(ntm - first, group_m);
+    mt = first + (id % per) % gsz;
+    nt = (id % per) / gsz;
+  } else {
+    mt = id / ntn;
+    nt = id % ntn;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int sm0 = (ABL & 4) ? 0 : m0, sn0 = (ABL & 4) ? 0 : n0;
+  const int G = p.K / BK;
+  const f16* __restrict__ A = (const f16*)p.A;
+  const f16* __restrict__ W = (const f16*)p.W;
+  const f16* srcA[IT_A];
+  const f16* srcW[IT_W];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int it = 0; it < IT_A; ++it) {
+    const int pch = it * NT + tid, row = pch / CPR, lch = (pch % CPR) ^ Swz<BK>::f(row);
+    srcA[it] = A + (size_t)min(sm0 + row, p.M - 1) * p.lda + lch * 8;
+  }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * WNC + j * 16 + fq * 4;
-      f32x4 v = acc[i][j];
-      if (n < p.N) {
-        if (p.bias) v += *(const f32x4*)(p.bias + n);
-        if (p.act == INK_ACT_GELU) {
+  for (int it = 0; it < IT_W; ++it) {
+    const int pch = it * NT + tid, row = pch / CPR, lch = (pch % CPR) ^ Swz<BK>::f(row);
+    srcW[it] = W + (size_t)min(sn0 + row, p.N - 1) * p.ldw + lch * 8;
+  }
+  auto dma = [&](int g, int slot) {
+    char* base = smem + slot * GRAN;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-        } else if (p.act == INK_ACT_RELU) {
+    for (int it = 0; it < IT_A; ++it)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[it] + g * BK), (lptr_t)(base + (it * NT + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (p.col_scale) v *= *(const f32x4*)(p.col_scale + n);
+    for (int it = 0; it < IT_W; ++it)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[it] + g * BK), (lptr_t)(base + TILE_A + (it * NT + wave * 64) * 16), 16, 0, 0);
+  };
+  auto slot_end = [&]() {
+    if (ABL & 2) return;
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // prologue: residual row indices, then RING-1 granules in flight (the launcher guarantees G >= RING-1), then
+  // the residual preload behind them; with a preload everything is drained once (the counted waits of the loop
+  // assume only DMA in flight), without one only granule 0 is waited for
+  int rr[TM];
+  residual_rows<TM>(rr, p, m0 + grp * 128, lane);
+#pragma unroll
+  for (int g = 0; g < RING - 1; ++g) dma(g, g);
+  f32x4 acc[TM][TN];
+  init_wave_tile<TM, TN>(acc, p, rr, n0 + wn * WNC, lane);
+  if (residual_preloaded(p)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * LOADS) : "memory");
+  }
+  slot_end();
+  if (grp == 1) slot_end();                         // the stagger: group 1 idles through slot 0
+  stamp_rt(1);
+
+  const int offA = (grp * 128 + fr) * ROWB;
+  const int offW = (wn * WNC + fr) * ROWB;
+  const int co = (fq ^ Swz<BK>::f(fr)) << 4;        // one k-step of 32 per granule: logical chunk = fq
+  f16x8 a[TM], w[TN];
+  int cslot = 0, islot = RING - 1;
+  for (int g = 0; g < G; ++g) {
+    // ---- LOAD slot
+    {
+      const char* bA = smem + cslot * GRAN;
+      const char* bW = bA + TILE_A;
+      if (!(ABL & 2) || g == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *(const f16x8*)(bA + offA + i * 16 * ROWB + co);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) w[j] = *(const f16x8*)(bW + offW + j * 16 * ROWB + co);
       }
-      if (f16o) {
-        *(f16x4*)(er + fr * EP + (j * 16 + fq * 4) * 2) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+      if (g + RING - 1 < G) {
+        dma(g + RING - 1, islot);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * LOADS) : "memory");   // granule g+1 of this wave landed
       } else {
-        *(f32x4*)(er + fr * EP + (j * 16 + fq * 4) * 4) = v;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
-    const int mbase = m0 + wm * (BM / WM) + i * 16;
-    if (f16o) {
-      constexpr int CPRW = WNC * 2 / 16;       // 16-B chunks per patch row
+    slot_end();
+    // ---- MFMA slot
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if (!(ABL & 1)) {
 #pragma unroll
-      for (int it = 0; it < (16 * CPRW + 63) / 64; ++it) {
-        const int c = it * 64 + lane;
-        const int row = c / CPRW, cc = c % CPRW;
-        const int m = mbase + row, n = n0 + wn * WNC + cc * 8;
-        if (c < 16 * CPRW && m < p.M && n < p.N) {
-          const int orow = p.row_map ? p.row_map[m] : m;
-          if (orow >= 0) {
-            f16x8 d = *(const f16x8*)(er + row * EP + cc * 16);
-            f16* dst = (f16*)p.C + (size_t)orow * p.ldc + n;
-            if (p.residual) {
-              const float* rp = p.residual + (size_t)orow * p.ldr + n;
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-              for (int e = 0; e < 8; ++e)
-                if (n + e < p.N) d[e] = (f16)((float)d[e] + rp[e]);
-            }
-            if (wide16 && n + 8 <= p.N) {
-              *(f16x8*)dst = d;
-            } else {
-              *(f16x4*)dst = (f16x4){d[0], d[1], d[2], d[3]};
-              if (n + 8 <= p.N) *(f16x4*)(dst + 4) = (f16x4){d[4], d[5], d[6], d[7]};
-            }
-          }
-        }
-      }
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], a[i], acc[i][j], 0, 0, 0);
     } else {
-      constexpr int CPRW = WNC * 4 / 16;
 #pragma unroll
-      for (int it = 0; it < (16 * CPRW + 63) / 64; ++it) {
-        const int c = it * 64 + lane;
-        const int row = c / CPRW, cc = c % CPRW;
-        const int m = mbase + row, n = n0 + wn * WNC + cc * 4;
-        if (c < 16 * CPRW && m < p.M && n < p.N) {
-          const int orow = p.row_map ? p.row_map[m] : m;
-          if (orow >= 0) {
-            f32x4 d = *(const f32x4*)(er + row * EP + cc * 16);
-            if (p.residual) d += *(const f32x4*)(p.residual + (size_t)orow * p.ldr + n);
-            *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + n) = d;
-          }
-        }
-      }
+      for (int i = 0; i < TM; ++i) acc[i][0][0] += (float)a[i][0] + (float)w[i & 3][1];
+    }
+    __builtin_amdgcn_s_setprio(0);
+    slot_end();
+    cslot = (cslot + 1 == RING) ? 0 : cslot + 1;
+    islot = (islot + 1 == RING) ? 0 : islot + 1;
+  }
+  if (grp == 0) slot_end();                         // group 0 idles through the last slot (same barrier count)
+  stamp_rt(2);
+
+  // ---- epilogue: the drained ring is the patch space
+  char* er = smem + wave * (16 * EP);
+  if (p.c_f16) {
+    store_wave_tile<TM, TN, true>(acc, p, er, m0 + grp * 128, n0 + wn * WNC, lane);
+  } else {
+    store_wave_tile<TM, TN, false>(acc, p, er, m0 + grp * 128, n0 + wn * WNC, lane);
+  }
+  if (ABL & 8) {
+    stamp_rt(3);                                    // stores issued (not retired)
+    if (wave == 0 && lane == 0) {
+      unsigned* out = (unsigned*)dbg_out + (size_t)blockIdx.x * 8;
+      out[0] = __builtin_amdgcn_s_getreg(63492);    // HW_ID
+      out[1] = __builtin_amdgcn_s_getreg(6164);     // XCC_ID
+      out[2] = wg_rt[0]; out[3] = wg_rt[1]; out[4] = wg_rt[2]; out[5] = wg_rt[3];
     }
   }
+}
+
+template <int RING, int ABL = 0>
+static int launch_gemm_pp(const InkGemm& p, hipStream_t s, int group_m) {
+  if (p.K / 32 < RING - 1) return 1;
+  constexpr int lds = RING * (256 + 256) * 32 * 2;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt_pp<RING, ABL>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+  (void)attr;
+  const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  hipLaunchKernelGGL((gemm_f16_nt_pp<RING, ABL>), dim3(ntiles), dim3(512), lds, s, p, group_m);
+  return ink_launch_status();
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NS, int ABL = 0>
@@ -317,6 +568,12 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     case 8: return launch_gemm<256, 256, 32, 2, 4, 4>(p, s);     // 128 KB, 8 waves
     case 9: return launch_gemm<256, 256, 64, 4, 2, 2>(p, s);     // 8 waves x (64x128)
     case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s, gm);    // 16 waves x (64x64)
+    case 40: return launch_gemm_pp<4>(p, s, gm);       // ping-pong, ring of 4 x K32 granules (128 KB)
+    case 42: return launch_gemm_pp<3>(p, s, gm);       // ring of 3 (96 KB)
+    case 43: return launch_gemm_pp<4, 1>(p, s, gm);    // ablations / instrumentation, see the kernel comment
+    case 44: return launch_gemm_pp<4, 3>(p, s, gm);
+    case 46: return launch_gemm_pp<4, 7>(p, s, gm);
+    case 48: return launch_gemm_pp<4, 8>(p, s, gm);
     case 21: return launch_gemm<256, 256, 64, 4, 4, 2, 1>(p, s, gm);  // ablation: no DMA after tile 1
     case 22: return launch_gemm<256, 256, 64, 4, 4, 2, 2>(p, s, gm);  // ablation: no MFMA
     case 23: return launch_gemm<256, 256, 64, 4, 4, 2, 3>(p, s, gm);  // ablation: no epilogue

@@ -70,6 +70,45 @@ def test_gemm_epilogue_scatter_residual_scale_f16(dev):
     assert (o16.double() - ref2).abs().max().item() < 2e-3 * ref2.abs().max().item()
 
 
+@pytest.mark.parametrize("variant", [-1, 0, 10, 40, 42])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16])
+def test_gemm_residual_preload_rowmap(dev, variant, out_dtype):
+    """Linear residual (no activation / layer scale) is preloaded into the accumulators before the K loop and the
+    epilogue is load-free: check it with a scattering row_map that drops rows, ragged M/N tiles, K deep enough for
+    several K-tiles, on every tile family (auto, 128x128, 16-wave 256x256, ping-pong rings 4 and 3)."""
+    from inklayer_amd import ops, _lib
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, N, K, R = 1100, 712, 320, 1000
+    a = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.1).half().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(R, N, generator=g).to(dev)
+    perm = torch.randperm(M, generator=g)
+    row_map = torch.full((M,), -1, dtype=torch.int32)
+    row_map[perm[:R]] = torch.arange(R, dtype=torch.int32)
+    row_map = row_map.to(dev)
+    ref = _ref_gemm(a, w, bias, None, None, res, row_map, R)
+    _lib.lib().ink_gemm_set_variant(variant)
+    try:
+        if out_dtype == torch.float32:
+            out = res.clone()                                  # in place: out IS the residual stream
+            ops.gemm(a, w, bias, residual=out, row_map=row_map, out=out)
+            tol = 1e-4
+        else:
+            out = torch.full((R, N), float("nan"), device=dev, dtype=torch.float16)
+            ops.gemm(a, w, bias, residual=res, row_map=row_map, out=out)
+            tol = 2e-3 * ref.abs().max().item()
+        # plain residual, no row map, exact tile multiples
+        a2 = a[:1024, :256].contiguous(); w2 = w[:512, :256].contiguous(); r2 = res[:1000].repeat(2, 1)[:1024, :512].contiguous()
+        o2 = ops.gemm(a2, w2, bias[:512].contiguous(), residual=r2, out_dtype=out_dtype)
+    finally:
+        _lib.lib().ink_gemm_set_variant(-1)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < tol
+    ref2 = _ref_gemm(a2, w2, bias[:512], None, None, r2, None, 1024)
+    assert (o2.double() - ref2).abs().max().item() < (1e-4 if out_dtype == torch.float32 else 2e-3 * ref2.abs().max().item())
+
+
 @pytest.mark.parametrize("C", [32, 64, 96, 256, 768, 1280, 2048])
 def test_layernorm_rows(dev, C):
     from inklayer_amd import ops

@@ -31,8 +31,11 @@ for (m, n, k, nm) in shapes:
         _lib.lib().ink_gemm_set_variant(v)
         ops.gemm(a, w, bias, out=out)
         if ref is None:
-            ref = (a[:512].float() @ w.float().t() + bias).half()
-        err = (out[:512].float() - ref.float()).abs().max().item()
+            idx = torch.cat([torch.arange(0, 512, device=dev), torch.randint(0, m, (2048,), device=dev),
+                             torch.arange(max(0, m - 300), m, device=dev)])
+            ref = (a[idx].float() @ w.float().t() + bias).half()
+        err = (out[idx].float() - ref.float()).abs().max().item()
+        out.zero_()
         t = ev_time(lambda: ops.gemm(a, w, bias, out=out))
         row.append(f"{2*m*n*k/t/1e9:6.0f}" + ("!" if err > 0.05 else " "))
     print(f"{nm} {m}x{n}x{k}".ljust(34), *[r.rjust(8) for r in row])
