@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define INK_ABI_VERSION 1
+#define INK_ABI_VERSION 2
 int ink_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -108,6 +108,12 @@ int ink_add_f32(const float* a, const float* b, int64_t n_b, float* out, int64_t
  * q_batch_rows / kv_batch_rows (int32 [n_batch], optional): first row of batch entry b in Q/O and
  * in K/V; NULL means b*n_q and b*n_k.  Lets many batch entries share one K/V (or Q) block, e.g.
  * SAM decoder layer 0 where the image keys are identical for all boxes of an image.
+ * tok_rows (int32 [n_batch, n_q], optional, bias_mode 2 only, n_q == n_k): token i of batch entry
+ *   (window) b lives in row tok_rows[b*n_q + i] of Q, K, V AND O, or is window padding (-1).  This
+ *   is window_partition / window_unpartition (SA/modeling/image_encoder.py:243-289) folded into
+ *   the attention: a padding token is skipped as a query and contributes the rows pad_k / pad_v
+ *   (f16 [n_heads*head_dim]: the k and v slices of the qkv bias, i.e. qkv(0)) as a key, exactly
+ *   what the reference computes for its zero-padded rows - without ever projecting them.
  * --------------------------------------------------------------------- */
 typedef struct InkAttn {
   const void* Q; const void* K; const void* V;   /* f16 */
@@ -123,6 +129,8 @@ typedef struct InkAttn {
   const void* rel_aug;                            /* mode 2 */
   const float* dense_bias; const float* dense_mask; /* mode 3 */
   int32_t n_mask; int32_t _pad;
+  const int32_t* tok_rows;                        /* mode 2, optional */
+  const void* pad_k; const void* pad_v;           /* f16 rows used for tok_rows == -1 keys */
 } InkAttn;
 int ink_flash_attn(const InkAttn* p, void* stream);
 
@@ -130,10 +138,13 @@ int ink_flash_attn(const InkAttn* p, void* stream);
  * (get_rel_pos + the two einsums of add_decomposed_rel_pos), divided by `scale`:
  *   rel_h[bh, q, j] = (Q[b, q, h, :] . rel_pos_h[q_h - j + S - 1, :]) / scale   (same for w).
  * rel_pos_h / rel_pos_w: f32 [2S-1, head_dim].  S == 64 writes out_h/out_w (f32 [.., 64]);
- * S <= 16 writes out_aug_f16 ([.., 32], rel_h then rel_w then zeros). */
+ * S <= 16 writes out_aug_f16 ([.., 32], rel_h then rel_w then zeros).
+ * tok_rows (optional, S <= 16 only): as in InkAttn - query i of window b is row tok_rows[b*S*S+i]
+ * of Q (-1: padding, its output row is left untouched). */
 int ink_relpos_bias(const void* Q, int64_t ldq, const float* rel_pos_h, const float* rel_pos_w,
                     int32_t S, int32_t n_batch, int32_t n_heads, int32_t head_dim, float scale,
-                    float* out_h, float* out_w, void* out_aug_f16, void* stream);
+                    const int32_t* tok_rows, float* out_h, float* out_w, void* out_aug_f16,
+                    void* stream);
 
 /* Sam.preprocess + PatchEmbed gather (SA/modeling/sam.py:164-174, image_encoder.py:364-395):
  * image_u8 is the ResizeLongestSide output, HWC uint8 [h, w, 3] (h, w <= L); writes the f16

@@ -34,6 +34,7 @@ class InkAttn(C.Structure):
         ("q_batch_rows", c_void_p), ("kv_batch_rows", c_void_p),
         ("rel_h", c_void_p), ("rel_w", c_void_p), ("rel_aug", c_void_p),
         ("dense_bias", c_void_p), ("dense_mask", c_void_p), ("n_mask", c_int), ("_pad", c_int),
+        ("tok_rows", c_void_p), ("pad_k", c_void_p), ("pad_v", c_void_p),
     ]
 
 
@@ -76,7 +77,7 @@ SIGNATURES = {
     "ink_sine_embed4": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "ink_box_refine": [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "ink_relpos_bias": [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
-                        c_void_p, c_void_p, c_void_p, c_void_p],
+                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 
 

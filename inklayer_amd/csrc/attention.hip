@@ -67,12 +67,20 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
   const int bh = blockIdx.x / nqb, qb = blockIdx.x % nqb;
   const int b = bh / p.n_heads, h = bh % p.n_heads;
   const int q_idx = qb * NW * 32 + wave * 32 + lq;
-  const bool q_ok = q_idx < p.n_q;
+  bool q_ok = q_idx < p.n_q;
   const int q_c = q_ok ? q_idx : p.n_q - 1;
 
   // ---- Q^T fragments (B operand): lane (col = q, half hh) holds Q[q][16 s + 8 hh + j]
   const int64_t qrow0 = p.q_batch_rows ? (int64_t)p.q_batch_rows[b] : (int64_t)b * p.n_q;
-  const f16* Qrow = (const f16*)p.Q + (qrow0 + q_c) * p.ldq + h * HD;
+  int64_t q_row = qrow0 + q_c;                     // row of this query in Q (and, with tok_rows, in O)
+  if constexpr (MODE == 2 && ALLKV) {
+    if (p.tok_rows) {
+      const int r = p.tok_rows[(int64_t)b * p.n_q + q_c];
+      q_ok = q_ok && r >= 0;                       // window padding: nothing to compute, nothing to store
+      q_row = r >= 0 ? r : 0;
+    }
+  }
+  const f16* Qrow = (const f16*)p.Q + q_row * p.ldq + h * HD;
   f16x8 qf[NQK];
 #pragma unroll
   for (int s = 0; s < NQKB; ++s) qf[s] = *(const f16x8*)(Qrow + 16 * s + 8 * hh);
@@ -205,8 +213,19 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
       const int ci = tid + it * NT;
       const int key = ci / CH, cc = ci % CH;
       if (ci < MAXT * 64 * CH && key < p.n_k) {
-        ka[it] = *(const f16x8*)(Kb + ((int64_t)key * p.ldk + cc * 8) * 2);
-        va[it] = *(const f16x8*)(Vb + ((int64_t)key * p.ldv + cc * 8) * 2);
+        if (MODE == 2 && p.tok_rows) {
+          const int r = p.tok_rows[(int64_t)b * p.n_k + key];
+          if (r >= 0) {
+            ka[it] = *(const f16x8*)((const f16*)p.K + (int64_t)r * p.ldk + h * HD + cc * 8);
+            va[it] = *(const f16x8*)((const f16*)p.V + (int64_t)r * p.ldv + h * HD + cc * 8);
+          } else {                                 // padded key: qkv(0) = the bias rows
+            ka[it] = *(const f16x8*)((const f16*)p.pad_k + h * HD + cc * 8);
+            va[it] = *(const f16x8*)((const f16*)p.pad_v + h * HD + cc * 8);
+          }
+        } else {
+          ka[it] = *(const f16x8*)(Kb + ((int64_t)key * p.ldk + cc * 8) * 2);
+          va[it] = *(const f16x8*)(Vb + ((int64_t)key * p.ldv + cc * 8) * 2);
+        }
       } else {
         ka[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         va[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -344,7 +363,9 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
   }
   const float inv = 1.0f / ltot;
   if (q_ok) {
-    f16* Orow = (f16*)p.O + ((int64_t)b * p.n_q + q_idx) * p.ldo + h * HD;  // O is always dense per batch entry
+    // O is dense per batch entry unless tok_rows scatters it back to token order
+    const int64_t o_row = (MODE == 2 && ALLKV && p.tok_rows) ? q_row : (int64_t)b * p.n_q + q_idx;
+    f16* Orow = (f16*)p.O + o_row * p.ldo + h * HD;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -446,8 +467,9 @@ template <int HD, int S, bool AUG>
 __global__ __launch_bounds__(256) void relpos_mfma_kernel(const f16* __restrict__ Q, int64_t ldq,
                                                           const float* __restrict__ Rh,
                                                           const float* __restrict__ Rw, int n_heads,
-                                                          float inv_scale, float* __restrict__ out_h,
-                                                          float* __restrict__ out_w, f16* __restrict__ out_aug) {
+                                                          float inv_scale, const int32_t* __restrict__ tok_rows,
+                                                          float* __restrict__ out_h, float* __restrict__ out_w,
+                                                          f16* __restrict__ out_aug) {
   constexpr int NQ = S * S;
   constexpr int RT = (2 * S - 1 + 31) / 32;       // 32-row tiles per table: 1 (S=14) or 4 (S=64)
   constexpr int ROWS = 2 * RT * 32;
@@ -478,9 +500,15 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const f16* __restrict_
   __syncthreads();
   for (int g = gb * GPB + wave; g < min(NQG, (gb + 1) * GPB); g += 4) {
     const int q = g * 32 + lq;
-    const bool q_ok = q < NQ;
+    bool q_ok = q < NQ;
     const int qc = q_ok ? q : NQ - 1;
-    const f16* qp = Q + ((int64_t)b * NQ + qc) * ldq + h * HD;
+    int64_t qrow = (int64_t)b * NQ + qc;
+    if (AUG && tok_rows) {
+      const int r = tok_rows[qrow];
+      q_ok = q_ok && r >= 0;
+      qrow = r >= 0 ? r : 0;
+    }
+    const f16* qp = Q + qrow * ldq + h * HD;
     f16x8 qf[HD / 16];
 #pragma unroll
     for (int s = 0; s < HD / 16; ++s) qf[s] = *(const f16x8*)(qp + 16 * s + 8 * hh);
@@ -537,6 +565,7 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
   INK_CHECK_ARG(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0);
   INK_CHECK_ARG((((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) == 0);
   INK_CHECK_ARG(((uintptr_t)p.O & 7) == 0);
+  INK_CHECK_ARG(!p.tok_rows || p.bias_mode == 2);
   hipStream_t s = (hipStream_t)stream;
   const int bhn = p.n_batch * p.n_heads;
 #define INK_FA_X(HD, MODE, NW, ALL)                                                                      \
@@ -556,6 +585,8 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
     INK_FA(80, 1, 4);
   } else if (p.head_dim == 80 && p.bias_mode == 2) {
     INK_CHECK_ARG(p.rel_aug && p.grid_w > 0 && p.grid_w <= 16 && p.n_k <= p.grid_w * p.grid_w && p.n_k <= 256);
+    INK_CHECK_ARG(!p.tok_rows || (p.n_q == p.n_k && p.pad_k && p.pad_v &&
+                                  (((uintptr_t)p.pad_k | (uintptr_t)p.pad_v) & 15) == 0));
     INK_FA_X(80, 2, 7, true);
   } else if (p.head_dim == 80 && p.bias_mode == 0) {
     INK_FA(80, 0, 4);
@@ -576,14 +607,14 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
 
 extern "C" int ink_relpos_bias(const void* Q, int64_t ldq, const float* rel_pos_h,
                                const float* rel_pos_w, int32_t S, int32_t n_batch,
-                               int32_t n_heads, int32_t head_dim, float scale, float* out_h,
-                               float* out_w, void* out_aug_f16, void* stream) {
+                               int32_t n_heads, int32_t head_dim, float scale, const int32_t* tok_rows,
+                               float* out_h, float* out_w, void* out_aug_f16, void* stream) {
   INK_CHECK_ARG(Q && rel_pos_h && rel_pos_w && head_dim == 80 && ldq % 8 == 0);
   INK_CHECK_ARG(n_batch > 0 && n_heads > 0 && S > 0 && scale > 0.f);
   if (out_aug_f16) {
     INK_CHECK_ARG(S <= 16);
   } else {
-    INK_CHECK_ARG(S == 64 && out_h && out_w);
+    INK_CHECK_ARG(S == 64 && out_h && out_w && !tok_rows);
   }
   const f16* q = (const f16*)Q;
   hipStream_t st = (hipStream_t)stream;
@@ -591,10 +622,10 @@ extern "C" int ink_relpos_bias(const void* Q, int64_t ldq, const float* rel_pos_
   if (out_aug_f16) {
     INK_CHECK_ARG(S == 14);
     hipLaunchKernelGGL((relpos_mfma_kernel<80, 14, true>), dim3(nbh), dim3(256), 0, st, q, ldq, rel_pos_h,
-                       rel_pos_w, n_heads, 1.0f / scale, out_h, out_w, (f16*)out_aug_f16);
+                       rel_pos_w, n_heads, 1.0f / scale, tok_rows, out_h, out_w, (f16*)out_aug_f16);
   } else {
     hipLaunchKernelGGL((relpos_mfma_kernel<80, 64, false>), dim3(nbh * 16), dim3(256), 0, st, q, ldq, rel_pos_h,
-                       rel_pos_w, n_heads, 1.0f / scale, out_h, out_w, (f16*)nullptr);
+                       rel_pos_w, n_heads, 1.0f / scale, (const int32_t*)nullptr, out_h, out_w, (f16*)nullptr);
   }
   return ink_launch_status();
 }

@@ -149,12 +149,16 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: in
                dense_bias: Optional[torch.Tensor] = None, dense_mask: Optional[torch.Tensor] = None,
                q_batch_rows: Optional[torch.Tensor] = None,
                kv_batch_rows: Optional[torch.Tensor] = None,
+               tok_rows: Optional[torch.Tensor] = None, pad_k: Optional[torch.Tensor] = None,
+               pad_v: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(scale*q@k^T + bias)@v for f16 row views q [.., >=H*hd], k/v [.., >=H*hd].
 
     q/k/v may be column slices of one packed qkv buffer (only the row stride matters).
     Batch entry b uses rows q_batch_rows[b] + [0, n_q) of q and kv_batch_rows[b] + [0, n_k) of
     k/v (defaults b*n_q, b*n_k); the output is dense [n_batch*n_q, H*hd].
+    With tok_rows (int32 [n_batch, n_q], rel_aug mode) token i of window b is row tok_rows[b, i] of
+    q, k, v and `out` (which is then required); -1 marks window padding, whose keys are pad_k / pad_v.
     """
     for t in (q, k, v):
         assert t.dtype == F16 and t.dim() == 2 and t.stride(1) == 1 and t.is_cuda
@@ -162,9 +166,16 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: in
         n_q = q.shape[0] // n_batch
     if n_k is None:
         n_k = k.shape[0] // n_batch
-    if out is None:
-        out = torch.empty((n_batch * n_q, n_heads * head_dim), device=q.device, dtype=F16)
-    assert out.dtype == F16 and out.shape[0] == n_batch * n_q and out.stride(1) == 1
+    if tok_rows is not None:
+        assert rel_aug is not None and out is not None and n_q == n_k
+        assert tok_rows.dtype == torch.int32 and tok_rows.is_cuda and tok_rows.numel() == n_batch * n_q
+        for t in (pad_k, pad_v):
+            assert t is not None and t.dtype == F16 and t.is_contiguous() and t.numel() == n_heads * head_dim
+        assert out.dtype == F16 and out.stride(1) == 1
+    else:
+        if out is None:
+            out = torch.empty((n_batch * n_q, n_heads * head_dim), device=q.device, dtype=F16)
+        assert out.dtype == F16 and out.shape[0] == n_batch * n_q and out.stride(1) == 1
     p = InkAttn()
     p.Q, p.K, p.V, p.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
     p.ldq, p.ldk, p.ldv, p.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
@@ -184,6 +195,8 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: in
     elif rel_aug is not None:
         assert rel_aug.dtype == F16 and rel_aug.is_contiguous()
         p.bias_mode, p.rel_aug = 2, rel_aug.data_ptr()
+        if tok_rows is not None:
+            p.tok_rows, p.pad_k, p.pad_v = tok_rows.data_ptr(), pad_k.data_ptr(), pad_v.data_ptr()
     elif rel_h is not None:
         assert rel_h.dtype == F32 and rel_w.dtype == F32
         assert rel_h.is_contiguous() and rel_w.is_contiguous()
@@ -195,7 +208,8 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: in
 
 
 def relpos_bias(q: torch.Tensor, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tensor, *, S: int,
-                n_batch: int, n_heads: int, head_dim: int, scale: float, out=None):
+                n_batch: int, n_heads: int, head_dim: int, scale: float, out=None,
+                tok_rows: Optional[torch.Tensor] = None):
     """SAM decomposed rel-pos terms / scale.  S == 64 -> (rel_h, rel_w) f32; S <= 16 -> rel_aug f16."""
     assert q.dtype == F16 and q.stride(1) == 1
     assert rel_pos_h.dtype == F32 and rel_pos_h.is_contiguous()
@@ -208,13 +222,16 @@ def relpos_bias(q: torch.Tensor, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tenso
                                               torch.empty((n, 64), device=q.device, dtype=F32))
         assert oh.numel() >= n * 64 and ow.numel() >= n * 64
         check(fn(q.data_ptr(), q.stride(0), rel_pos_h.data_ptr(), rel_pos_w.data_ptr(), S, n_batch,
-                 n_heads, head_dim, scale, oh.data_ptr(), ow.data_ptr(), None, _stream()),
+                 n_heads, head_dim, scale, None, oh.data_ptr(), ow.data_ptr(), None, _stream()),
               "ink_relpos_bias")
         return oh, ow
     aug = out if out is not None else torch.empty((n, 32), device=q.device, dtype=F16)
     assert aug.numel() >= n * 32
+    if tok_rows is not None:
+        assert tok_rows.dtype == torch.int32 and tok_rows.is_cuda and tok_rows.numel() == n_batch * S * S
     check(fn(q.data_ptr(), q.stride(0), rel_pos_h.data_ptr(), rel_pos_w.data_ptr(), S, n_batch,
-             n_heads, head_dim, scale, None, None, aug.data_ptr(), _stream()), "ink_relpos_bias")
+             n_heads, head_dim, scale, tok_rows.data_ptr() if tok_rows is not None else None,
+             None, None, aug.data_ptr(), _stream()), "ink_relpos_bias")
     return aug
 
 

@@ -113,6 +113,12 @@ class SamEngine:
                 w[f"b{i}.{n}"] = f(p + n)
             for n in ("attn.qkv.weight", "attn.proj.weight", "mlp.lin1.weight", "mlp.lin2.weight"):
                 w[f"b{i}.{n}"] = h(p + n)
+            if i not in cfg.global_attn_indexes:
+                # window padding (image_encoder.py:256-259 pads AFTER norm1 with zeros): the k / v rows of a
+                # padded token are qkv(0) = the bias, rounded to f16 exactly like a projected row would be
+                qb = w[f"b{i}.attn.qkv.bias"]
+                w[f"b{i}.pad_k"] = qb[D:2 * D].to(F16).contiguous()
+                w[f"b{i}.pad_v"] = qb[2 * D:].to(F16).contiguous()
         w["neck0.w"] = h("image_encoder.neck.0.weight", (E, D))
         w["neck1.w"], w["neck1.b"] = f("image_encoder.neck.1.weight"), f("image_encoder.neck.1.bias")
         # 3x3 conv weight re-laid out as [co][(ky,kx,ci)] to match the NHWC im2col
@@ -194,9 +200,9 @@ class SamEngine:
         e = lambda *s, dt=F16: torch.empty(s, device=dev, dtype=dt)
         self.buf_patches = e(B * T, 3 * P * P)
         self.x = e(B * T, D, dt=F32)
-        self.y = e(B * Mw, D)
-        self.qkv = e(B * Mw, 3 * D)
-        self.att = e(B * Mw, D)
+        self.y = e(B * T, D)
+        self.qkv = e(B * T, 3 * D)
+        self.att = e(B * T, D)
         self.hid = e(B * T, int(D * cfg.mlp_ratio))
         H = cfg.num_heads
         self.rel_aug = e(B * nwin * nwin * H * ws * ws, 32)
@@ -234,19 +240,23 @@ class SamEngine:
                                    rel_h=rh, rel_w=rw, grid_w=cfg.grid, out=self.att[:B * T])
                 ops.gemm(o, w[k + "attn.proj.weight"], w[k + "attn.proj.bias"], residual=x, out=x)
             else:
+                # windowed block: everything stays in token order; window_partition / window_unpartition
+                # (image_encoder.py:243-289) is the token-row map the attention gathers and scatters through,
+                # so the 19.6 % padding rows (70x70 vs 64x64) are never normalised, projected or written
                 wm = self.win_map[:B * Mw]
-                y = ops.layernorm_rows(x, w[k + "norm1.weight"], w[k + "norm1.bias"], 1e-6, gather=wm,
-                                       out=self.y[:B * Mw])
-                qkv = ops.gemm(y, w[k + "attn.qkv.weight"], w[k + "attn.qkv.bias"], out=self.qkv[:B * Mw])
+                y = ops.layernorm_rows(x, w[k + "norm1.weight"], w[k + "norm1.bias"], 1e-6,
+                                       out=self.y[:B * T])
+                qkv = ops.gemm(y, w[k + "attn.qkv.weight"], w[k + "attn.qkv.bias"], out=self.qkv[:B * T])
                 q, kk, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
                 nb = B * self.nwin * self.nwin
                 aug = ops.relpos_bias(q, w[k + "attn.rel_pos_h"], w[k + "attn.rel_pos_w"],
                                       S=cfg.window_size, n_batch=nb, n_heads=H, head_dim=80,
-                                      scale=self.scale, out=self.rel_aug)
+                                      scale=self.scale, out=self.rel_aug, tok_rows=wm)
                 o = ops.flash_attn(q, kk, v, n_batch=nb, n_heads=H, head_dim=80, scale=self.scale,
-                                   rel_aug=aug, grid_w=cfg.window_size, out=self.att[:B * Mw])
-                ops.gemm(o, w[k + "attn.proj.weight"], w[k + "attn.proj.bias"], residual=x, row_map=wm,
-                         out=x)
+                                   n_q=cfg.window_size ** 2, n_k=cfg.window_size ** 2,
+                                   rel_aug=aug, grid_w=cfg.window_size, tok_rows=wm,
+                                   pad_k=w[k + "pad_k"], pad_v=w[k + "pad_v"], out=self.att[:B * T])
+                ops.gemm(o, w[k + "attn.proj.weight"], w[k + "attn.proj.bias"], residual=x, out=x)
             y = ops.layernorm_rows(x, w[k + "norm2.weight"], w[k + "norm2.bias"], 1e-6, out=self.y[:B * T])
             hd = ops.gemm(y, w[k + "mlp.lin1.weight"], w[k + "mlp.lin1.bias"], act="gelu",
                           out=self.hid[:B * T])

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 4
     for s in syms:
         assert hasattr(l, s), f"{s} declared in inklayer_hip.h but not exported"
-    assert l.ink_abi_version() == 1
+    assert l.ink_abi_version() == 2
 
 
 def test_python_binding_covers_header():

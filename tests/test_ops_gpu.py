@@ -192,3 +192,46 @@ def test_flash_attn_hd32(dev, nq, nk):
     ref = ((qd @ kd.transpose(-1, -2)) * hd ** -0.5).softmax(-1) @ vd
     ref = ref.transpose(1, 2).reshape(B * nq, H * hd)
     assert (out.double() - ref).abs().max().item() < 3e-3
+
+
+def test_window_attention_token_rows_equals_padded_layout(dev):
+    """tok_rows folds window_partition / window_unpartition (image_encoder.py:243-289) into the attention:
+    gathering q/k/v rows, substituting qkv(0) for padded keys and scattering the output must give exactly what
+    the padded window layout gives (same arithmetic, same order)."""
+    from inklayer_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, grid, S, H, hd = 2, 20, 14, 2, 80
+    D, T, nwin = H * hd, grid * grid, 2
+    Mw = nwin * nwin * S * S
+    r = torch.arange(B * Mw)
+    b, rr = r // Mw, r % Mw
+    win, pos = rr // (S * S), rr % (S * S)
+    y, x = (win // nwin) * S + pos // S, (win % nwin) * S + pos % S
+    m = torch.where((y < grid) & (x < grid), b * T + y * grid + x, torch.full_like(r, -1))
+    assert int((m >= 0).sum()) == B * T
+    wm = m.to(torch.int32).to(dev)
+    qkv_tok = (torch.randn(B * T, 3 * D, generator=g) * 0.5).half().to(dev)
+    pad_k = (torch.randn(D, generator=g) * 0.5).half().to(dev)
+    pad_v = (torch.randn(D, generator=g) * 0.5).half().to(dev)
+    rel_h = (torch.randn(2 * S - 1, hd, generator=g) * 0.2).to(dev)
+    rel_w = (torch.randn(2 * S - 1, hd, generator=g) * 0.2).to(dev)
+    scale = hd ** -0.5
+    # padded layout: padded rows are [q = 0, pad_k, pad_v]
+    pad_row = torch.cat([torch.zeros(D, device=dev, dtype=torch.float16), pad_k, pad_v])
+    qkv_win = torch.where((wm >= 0)[:, None], qkv_tok[wm.clamp(min=0).long()], pad_row[None, :]).contiguous()
+    nb = B * nwin * nwin
+    kw = dict(n_batch=nb, n_heads=H, head_dim=hd, scale=scale)
+    aug_ref = ops.relpos_bias(qkv_win[:, :D], rel_h, rel_w, S=S, **kw)
+    o_ref = ops.flash_attn(qkv_win[:, :D], qkv_win[:, D:2 * D], qkv_win[:, 2 * D:], rel_aug=aug_ref, grid_w=S, **kw)
+    aug = ops.relpos_bias(qkv_tok[:, :D], rel_h, rel_w, S=S, tok_rows=wm, **kw,
+                          out=torch.zeros(nb * H * S * S, 32, device=dev, dtype=torch.float16))
+    out = torch.full((B * T, D), float("nan"), device=dev, dtype=torch.float16)
+    ops.flash_attn(qkv_tok[:, :D], qkv_tok[:, D:2 * D], qkv_tok[:, 2 * D:], n_q=S * S, n_k=S * S, rel_aug=aug,
+                   grid_w=S, tok_rows=wm, pad_k=pad_k, pad_v=pad_v, out=out, **kw)
+    assert torch.isfinite(out).all()                       # every token row written exactly once
+    keep = wm >= 0
+    assert torch.equal(out[wm[keep].long()], o_ref[keep])
+    # the rel-pos rows of real queries agree too
+    a4 = aug.view(nb, H, S * S, 32); r4 = aug_ref.view(nb, H, S * S, 32)
+    k4 = keep.view(nb, 1, S * S, 1).expand_as(a4)
+    assert torch.equal(a4[k4], r4[k4])
