@@ -183,15 +183,24 @@ def main():
     assert len(res) == B and res[0].masks.shape == (args.boxes, 1024, 1024)
 
     if rank == 0:
-        traffic = None
-        pmc = ROOT / "profiles" / "r01_gemm_pmc.json"
-        if pmc.exists():      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (see DESIGN.md §7)
-            traffic = json.loads(pmc.read_text()).get("traffic_bytes_per_launch")
         from inklayer_amd import _lib
         gemm_ms = sum(t[1].elapsed_time(t[2]) for t in trace)
         gemm_flops = sum(t[0] for t in trace)
-        # the dominant kernel = the 256x256x64 / 16-wave tile variant: its launches, flops, bytes and durations
-        dom = [t for t in trace if _lib.lib().ink_gemm_query_variant(t[3][0], t[3][1], t[3][2]) == 10]
+        # the dominant kernel = the tile variant with the largest total time: its launches, flops, bytes, durations
+        names = {45: "gemm_f16_nt_pp<4,5> (ping-pong 256x320x32 tile, 8 waves: dense projections of SAM ViT-H)",
+                 10: "gemm_f16_nt<256,256,64,4,4,2> (16-wave 256x256 tile: DINO FFN and other large projections)",
+                 0: "gemm_f16_nt<128,128,64,2,2,2>", 32: "gemm_f16_nt<128,128,32,2,2,2>"}
+        by_var = {}
+        for t in trace:
+            by_var.setdefault(_lib.lib().ink_gemm_query_variant(t[3][0], t[3][1], t[3][2]), []).append(t)
+        dom_var = max(by_var, key=lambda v: sum(t[1].elapsed_time(t[2]) for t in by_var[v]))
+        dom = by_var[dom_var]
+        traffic = None
+        pmc = ROOT / "profiles" / "r01_gemm_pmc.json"
+        if pmc.exists():      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (see DESIGN.md §7)
+            pj = json.loads(pmc.read_text())
+            if pj.get("variant") == dom_var:
+                traffic = pj.get("traffic_bytes_per_launch")
         dom_ms = sum(t[1].elapsed_time(t[2]) for t in dom)
         dom_flops = sum(t[0] for t in dom)
         abytes = lambda k: (2.0 * (k[0] * k[2] + k[1] * k[2])                       # A + W in f16
@@ -209,7 +218,7 @@ def main():
                                    "1024x1024 synthetic sketches, 16 boxes/sketch, random-init weights",
                        "global_batch": B * world, "boxes_per_sketch": args.boxes,
                        "parallelism": f"image-parallel x{world}", "weight_broadcast_s": round(bcast_s, 3)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16_nt<256,256,64,4,4,2> (dense projections of ViT-H / DINO FFN)",
+            "roofline": {"bound": "mfma", "kernel": names.get(dom_var, str(dom_var)),
                          "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_TFLOPS, "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",

@@ -15,6 +15,7 @@
 // Epilogue (fused, f32): +bias, GELU/ReLU, *col_scale, +residual, optional row
 // scatter (window-unpartition / crop / un-shift), f32 or f16 store.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "../../include/inklayer_hip.h"
@@ -45,37 +46,40 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //   * the residual of the linear case (no activation, no layer scale - every large GEMM of the pipeline) is
 //     loaded straight into the accumulators before the K loop, row-mapped, and the MFMAs accumulate on top of it
 //     (the four j-loads of a row cover 256 contiguous bytes; they overlap the pipeline fill);
-//   * bias and the output row of every store chunk are loaded before the first store;
+//   * the output rows (wave_rows, one per accumulator row, redistributed with ds_bpermute) and the bias are
+//     loaded before the first store;
 //   * the rare non-linear residual / layer-scale loads stay in the loop, each used inside its own branch.
 __device__ __forceinline__ bool residual_preloaded(const InkGemm& p) {
   return p.residual && p.act == INK_ACT_NONE && !p.col_scale;
 }
 
-// residual rows of the accumulator layout (-1: nothing to preload); issued BEFORE the first K-tile DMA so that the
-// wait for them is a counted one, the residual loads themselves go out behind the DMA (init_wave_tile)
+// Output row of every accumulator row of the wave tile (lane & 15 = row within the 16-row slab), -1 = outside M or
+// dropped by the row map.  Loaded ONCE, before the first K-tile DMA: the residual preload indexes the residual
+// with it and the epilogue redistributes it across lanes with ds_bpermute (no load next to the stores).
 template <int TM>
-__device__ __forceinline__ void residual_rows(int (&rr)[TM], const InkGemm& p, int mw, int lane) {
-  const bool pre = residual_preloaded(p);
+__device__ __forceinline__ void wave_rows(int (&rows)[TM], const InkGemm& p, int mw, int lane) {
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti) {
     const int m = mw + ti * 16 + (lane & 15);
     int r = -1;
-    if (pre && m < p.M) r = p.row_map ? p.row_map[m] : m;
-    rr[ti] = r;
+    if (m < p.M) r = p.row_map ? p.row_map[m] : m;
+    rows[ti] = r;
   }
 }
 
 template <int TM, int TN>
-__device__ __forceinline__ void init_wave_tile(f32x4 (&acc)[TM][TN], const InkGemm& p, const int (&rr)[TM], int nw,
+__device__ __forceinline__ void init_wave_tile(f32x4 (&acc)[TM][TN], const InkGemm& p, const int (&rows)[TM], int nw,
                                                int lane) {
   const int fq = lane >> 4;
+  const bool pre = residual_preloaded(p);
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti) {
-    const float* rp = p.residual + (size_t)max(rr[ti], 0) * p.ldr + nw + fq * 4;
+    const int r = pre ? rows[ti] : -1;
+    const float* rp = p.residual + (size_t)max(r, 0) * p.ldr + nw + fq * 4;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       acc[ti][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (rr[ti] >= 0 && nw + j * 16 + fq * 4 < p.N) acc[ti][j] = *(const f32x4*)(rp + j * 16);
+      if (r >= 0 && nw + j * 16 + fq * 4 < p.N) acc[ti][j] = *(const f32x4*)(rp + j * 16);
     }
   }
 }
@@ -83,43 +87,39 @@ __device__ __forceinline__ void init_wave_tile(f32x4 (&acc)[TM][TN], const InkGe
 // Each 16-row slab goes through a wave-private LDS patch so that HBM sees whole row segments (16 B per lane,
 // 128 B (f16) / 256 B (f32) contiguous per row); bias / activation / layer-scale are applied on the way in.
 template <int TM, int TN, bool F16O>
-__device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkGemm& p, char* er, int mw, int nw,
-                                                int lane) {
+__device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkGemm& p, char* er,
+                                                const int (&rows)[TM], int nw, int lane) {
   constexpr int WNC = TN * 16, EP = WNC * 4 + 16;
   constexpr int ES = F16O ? 8 : 4;                 // elements per 16-B chunk of the output row
-  constexpr int CPRW = WNC / ES;                   // chunks per patch row (divides 64)
+  constexpr int CPRW = WNC / ES;                   // chunks per patch row
   constexpr int NIT = (16 * CPRW + 63) / 64;       // chunk rounds per slab
-  constexpr int RPI = 64 / CPRW;                   // patch rows per round
   const int fr = lane & 15, fq = lane >> 4;
   const bool wide16 = F16O && (p.ldc % 8 == 0);
   const bool res_late = p.residual && !residual_preloaded(p);
-  const int c_row = lane / CPRW, c_n = nw + (lane % CPRW) * ES;    // the lane's chunk column is the same every round
+  // chunk c = it*64 + lane of a slab: patch row c / CPRW, chunk column c % CPRW (the same for every slab)
+  int row_of[NIT], n_of[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 64 + lane;
+    row_of[it] = c < 16 * CPRW ? c / CPRW : 16;
+    n_of[it] = nw + (c % CPRW) * ES;
+  }
 
-  // every load up front: output rows of the store chunks (-1 = nothing to store), bias
-  int orow[TM][NIT];
-#pragma unroll
-  for (int ti = 0; ti < TM; ++ti)
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int row = it * RPI + c_row;
-      const int m = mw + ti * 16 + row;
-      int r = -1;
-      if (row < 16 && m < p.M && c_n < p.N) r = p.row_map ? p.row_map[m] : m;
-      orow[ti][it] = r;
-    }
-  f32x4 bv[TN];
+  // the only load of the epilogue, before the first store: bias
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = nw + j * 16 + fq * 4;
-    bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias && n < p.N) bv[j] = *(const f32x4*)(p.bias + n);
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti) acc[ti][j] += bv;     // unconditional: no copy of the array at a join
   }
 
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      f32x4 v = acc[ti][j] + bv[j];
+      f32x4 v = acc[ti][j];
       if (p.act == INK_ACT_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -139,9 +139,12 @@ __device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkG
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int r = orow[ti][it];
+      // output row of patch row row_of[it]: held by the lanes with (lane & 15) == that row
+      int r = __builtin_amdgcn_ds_bpermute((row_of[it] & 15) << 2, rows[ti]);
+      if (row_of[it] >= 16 || n_of[it] >= p.N) r = -1;
       if (r >= 0) {
-        const char* src = er + (it * RPI + c_row) * EP + (c_n - nw) * (F16O ? 2 : 4);
+        const int c_n = n_of[it];
+        const char* src = er + row_of[it] * EP + (c_n - nw) * (F16O ? 2 : 4);
         if (F16O) {
           f16x8 d = *(const f16x8*)src;
           f16* dst = (f16*)p.C + (size_t)r * p.ldc + c_n;
@@ -240,8 +243,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
       __builtin_amdgcn_global_load_lds((gptr_t)(srcW[it] + kt * BK), (lptr_t)(base + TILE_A + (it * NT + wave * 64) * 16), 16, 0, 0);
   };
 
-  int rr[TM];
-  residual_rows<TM>(rr, p, m0 + wm * (BM / WM), lane);
+  int rows[TM];
+  wave_rows<TM>(rows, p, m0 + wm * (BM / WM), lane);
   f32x4 acc[TM][TN];
 
   const int fr = lane & 15, fq = lane >> 4;
@@ -255,23 +258,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
     const char* bW = bA + TILE_A;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
-      f16x8 a[TM], w[TN];
+      constexpr int AG = TM > 4 ? 4 : TM;    // A fragments live at a time (big wave tiles: registers)
+      f16x8 a[AG], w[TN];
       const int co = ((kk * 4 + fq) ^ swz) << 4;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *(const f16x8*)(bA + offA + i * 16 * ROWB + co);
 #pragma unroll
       for (int j = 0; j < TN; ++j) w[j] = *(const f16x8*)(bW + offW + j * 16 * ROWB + co);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i0 = 0; i0 < TM; i0 += AG) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], a[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < AG; ++i) a[i] = *(const f16x8*)(bA + offA + (i0 + i) * 16 * ROWB + co);
+#pragma unroll
+        for (int i = 0; i < AG; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], a[i], acc[i0 + i][j], 0, 0, 0);
+      }
     }
   };
 
   if constexpr (NS == 2) {
     stage(0, 0);
-    init_wave_tile<TM, TN>(acc, p, rr, n0 + wn * (BN / WN), lane);
+    init_wave_tile<TM, TN>(acc, p, rows, n0 + wn * (BN / WN), lane);
     for (int kt = 0; kt < nk; ++kt) {
       // the LDS-DMA of tile kt is tracked by vmcnt only: drain it EXPLICITLY before the barrier (whether
       // __syncthreads() alone emits the vmcnt wait depends on what else the compiler sees in flight)
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
       if (s < nk) stage(s, s);
-    init_wave_tile<TM, TN>(acc, p, rr, n0 + wn * (BN / WN), lane);
+    init_wave_tile<TM, TN>(acc, p, rows, n0 + wn * (BN / WN), lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the counted waits below assume only DMA in flight)
     int cur = 0, nxt = NS - 1;
     for (int kt = 0; kt < nk; ++kt) {
@@ -319,9 +326,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
   __syncthreads();                             // every wave is done reading the last K-tile
   char* er = smem + wave * (16 * EP);
   if (p.c_f16) {
-    store_wave_tile<TM, TN, true>(acc, p, er, m0 + wm * (BM / WM), n0 + wn * WNC, lane);
+    store_wave_tile<TM, TN, true>(acc, p, er, rows, n0 + wn * WNC, lane);
   } else {
-    store_wave_tile<TM, TN, false>(acc, p, er, m0 + wm * (BM / WM), n0 + wn * WNC, lane);
+    store_wave_tile<TM, TN, false>(acc, p, er, rows, n0 + wn * WNC, lane);
   }
 }
 
@@ -342,14 +349,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
 // ABL (ablation / instrumentation builds, reachable through ink_gemm_set_variant only): 1 no MFMA, 2 no LDS
 // reads / barriers, 4 every tile reads tile (0,0) (all L2 hits), 8 every workgroup writes (HW_ID, XCC_ID,
 // t_entry, t_filled, t_loop_end, t_stores_issued) in 100 MHz ticks through p.residual (tools/gemm_stamps.py).
-template <int RING, int ABL = 0>
+// TN = 4: 256x256 tile, TN = 5: 256x320 (wave tile 128 x 16*TN; 160 accumulator VGPRs).  LATE_A keeps only four of
+// the eight A fragments live: rows 4-7 are read DURING the MFMA slot into the registers of rows 0-3 as soon as
+// those have issued their MFMAs.  A granule is then still being read one slot later, so its ring slot may only be
+// refilled one granule later: the DMA runs RING-2 granules ahead instead of RING-1.
+template <int RING, int TN, int ABL = 0, bool LATE_A = (TN > 4)>
 __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
-  constexpr int BM = 256, BN = 256, BK = 32, NT = 512;
+  constexpr int BM = 256, BN = 64 * TN, BK = 32, NT = 512;
   constexpr int CPR = BK / 8, ROWB = BK * 2;
   constexpr int TILE_A = BM * ROWB, TILE_W = BN * ROWB, GRAN = TILE_A + TILE_W;   // 32 KiB
   constexpr int IT_A = (BM * CPR) / NT, IT_W = (BN * CPR) / NT;                    // 2 + 2 DMA per thread
-  constexpr int LOADS = IT_A + IT_W;
-  constexpr int TM = 8, TN = 4, WNC = 64;
+  constexpr bool W_TAIL = (BN * CPR) % NT != 0;       // 320 rows: a third, half-populated round (waves 0-3 = group 0)
+  static_assert(!W_TAIL || (BN * CPR) % NT == NT / 2, "tail is exactly the first four waves");
+  constexpr int LOADS = IT_A + IT_W;                  // per wave of group 1; group 0 issues one more with W_TAIL
+  constexpr int TM = 8, WNC = 16 * TN;
+  constexpr int AHEAD = LATE_A ? RING - 2 : RING - 1;   // granules the DMA runs ahead of the LOAD slot
+  constexpr int AG = LATE_A ? 4 : TM;                   // A fragments live at a time
+  static_assert(AHEAD >= 1, "ring too small");
   constexpr int EP = WNC * 4 + 16;
   static_assert(8 * 16 * EP <= RING * GRAN, "patch fits");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -385,15 +401,15 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   const f16* __restrict__ A = (const f16*)p.A;
   const f16* __restrict__ W = (const f16*)p.W;
   const f16* srcA[IT_A];
-  const f16* srcW[IT_W];
+  const f16* srcW[IT_W + (W_TAIL ? 1 : 0)];
 #pragma unroll
   for (int it = 0; it < IT_A; ++it) {
     const int pch = it * NT + tid, row = pch / CPR, lch = (pch % CPR) ^ Swz<BK>::f(row);
     srcA[it] = A + (size_t)min(sm0 + row, p.M - 1) * p.lda + lch * 8;
   }
 #pragma unroll
-  for (int it = 0; it < IT_W; ++it) {
-    const int pch = it * NT + tid, row = pch / CPR, lch = (pch % CPR) ^ Swz<BK>::f(row);
+  for (int it = 0; it < IT_W + (W_TAIL ? 1 : 0); ++it) {
+    const int pch = it * NT + tid, row = min(pch / CPR, BN - 1), lch = (pch % CPR) ^ Swz<BK>::f(row);
     srcW[it] = W + (size_t)min(sn0 + row, p.N - 1) * p.ldw + lch * 8;
   }
   auto dma = [&](int g, int slot) {
@@ -404,6 +420,17 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
 #pragma unroll
     for (int it = 0; it < IT_W; ++it)
       __builtin_amdgcn_global_load_lds((gptr_t)(srcW[it] + g * BK), (lptr_t)(base + TILE_A + (it * NT + wave * 64) * 16), 16, 0, 0);
+    if (W_TAIL && grp == 0)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[IT_W] + g * BK), (lptr_t)(base + TILE_A + (IT_W * NT + wave * 64) * 16), 16, 0, 0);
+  };
+  // counted wait that leaves the `ahead` most recent granules of THIS wave in flight
+  auto wait_ahead = [&](auto ahead_c) {
+    constexpr int ahead = decltype(ahead_c)::value;
+    if (W_TAIL && grp == 0) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ahead * (LOADS + 1)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ahead * LOADS) : "memory");
+    }
   };
   auto slot_end = [&]() {
     if (ABL & 2) return;
@@ -415,16 +442,16 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   // prologue: residual row indices, then RING-1 granules in flight (the launcher guarantees G >= RING-1), then
   // the residual preload behind them; with a preload everything is drained once (the counted waits of the loop
   // assume only DMA in flight), without one only granule 0 is waited for
-  int rr[TM];
-  residual_rows<TM>(rr, p, m0 + grp * 128, lane);
+  int rows[TM];
+  wave_rows<TM>(rows, p, m0 + grp * 128, lane);
 #pragma unroll
-  for (int g = 0; g < RING - 1; ++g) dma(g, g);
+  for (int g = 0; g < AHEAD; ++g) dma(g, g);
   f32x4 acc[TM][TN];
-  init_wave_tile<TM, TN>(acc, p, rr, n0 + wn * WNC, lane);
+  init_wave_tile<TM, TN>(acc, p, rows, n0 + wn * WNC, lane);
   if (residual_preloaded(p)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * LOADS) : "memory");
+    wait_ahead(std::integral_constant<int, AHEAD - 1>{});
   }
   slot_end();
   if (grp == 1) slot_end();                         // the stagger: group 1 idles through slot 0
@@ -433,25 +460,23 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   const int offA = (grp * 128 + fr) * ROWB;
   const int offW = (wn * WNC + fr) * ROWB;
   const int co = (fq ^ Swz<BK>::f(fr)) << 4;        // one k-step of 32 per granule: logical chunk = fq
-  f16x8 a[TM], w[TN];
-  int cslot = 0, islot = RING - 1;
+  f16x8 a[AG], w[TN];
+  int cslot = 0, islot = AHEAD % RING;
   for (int g = 0; g < G; ++g) {
+    const char* bA = smem + cslot * GRAN;
+    const char* bW = bA + TILE_A;
     // ---- LOAD slot
-    {
-      const char* bA = smem + cslot * GRAN;
-      const char* bW = bA + TILE_A;
-      if (!(ABL & 2) || g == 0) {
+    if (!(ABL & 2) || g == 0) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *(const f16x8*)(bA + offA + i * 16 * ROWB + co);
+      for (int i = 0; i < AG; ++i) a[i] = *(const f16x8*)(bA + offA + i * 16 * ROWB + co);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) w[j] = *(const f16x8*)(bW + offW + j * 16 * ROWB + co);
-      }
-      if (g + RING - 1 < G) {
-        dma(g + RING - 1, islot);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * LOADS) : "memory");   // granule g+1 of this wave landed
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      for (int j = 0; j < TN; ++j) w[j] = *(const f16x8*)(bW + offW + j * 16 * ROWB + co);
+    }
+    if (g + AHEAD < G) {
+      dma(g + AHEAD, islot);
+      wait_ahead(std::integral_constant<int, AHEAD - 1>{});   // granule g+1 of this wave landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     slot_end();
     // ---- MFMA slot
@@ -460,13 +485,21 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
     __builtin_amdgcn_s_setprio(1);
     if (!(ABL & 1)) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i0 = 0; i0 < TM; i0 += AG) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], a[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < AG; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], a[i], acc[i0 + i][j], 0, 0, 0);
+          if (LATE_A && i0 + AG < TM) {     // this fragment register is free: fetch the row AG further down
+            a[i] = *(const f16x8*)(bA + offA + (i0 + AG + i) * 16 * ROWB + co);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) acc[i][0][0] += (float)a[i][0] + (float)w[i & 3][1];
+      for (int i = 0; i < AG; ++i) acc[i][0][0] += (float)a[i][0] + (float)w[i % TN][1];
     }
     __builtin_amdgcn_s_setprio(0);
     slot_end();
@@ -479,9 +512,9 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   // ---- epilogue: the drained ring is the patch space
   char* er = smem + wave * (16 * EP);
   if (p.c_f16) {
-    store_wave_tile<TM, TN, true>(acc, p, er, m0 + grp * 128, n0 + wn * WNC, lane);
+    store_wave_tile<TM, TN, true>(acc, p, er, rows, n0 + wn * WNC, lane);
   } else {
-    store_wave_tile<TM, TN, false>(acc, p, er, m0 + grp * 128, n0 + wn * WNC, lane);
+    store_wave_tile<TM, TN, false>(acc, p, er, rows, n0 + wn * WNC, lane);
   }
   if (ABL & 8) {
     stamp_rt(3);                                    // stores issued (not retired)
@@ -494,16 +527,17 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   }
 }
 
-template <int RING, int ABL = 0>
+template <int RING, int TN = 4, int ABL = 0>
 static int launch_gemm_pp(const InkGemm& p, hipStream_t s, int group_m) {
-  if (p.K / 32 < RING - 1) return 1;
-  constexpr int lds = RING * (256 + 256) * 32 * 2;
+  if (p.K / 32 < RING) return 1;
+  constexpr int BN = 64 * TN;
+  constexpr int lds = RING * (256 + BN) * 32 * 2;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt_pp<RING, ABL>,
+  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt_pp<RING, TN, ABL>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)attr;
-  const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  hipLaunchKernelGGL((gemm_f16_nt_pp<RING, ABL>), dim3(ntiles), dim3(512), lds, s, p, group_m);
+  const int ntiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL((gemm_f16_nt_pp<RING, TN, ABL>), dim3(ntiles), dim3(512), lds, s, p, group_m);
   return ink_launch_status();
 }
 
@@ -521,10 +555,13 @@ static int launch_gemm(const InkGemm& p, hipStream_t s, int group_m = 1) {
 }  // namespace
 
 static int g_variant = -1;
-// shape heuristic (tools/gemm_sweep.py on MI355X): the 16-wave 256x256 tile wins whenever it fills the chip
-// (>= ~200 tiles) and N does not waste a large part of a 256-wide tile; else the 128x128 tile.
+// shape heuristic (tools/gemm_sweep.py on MI355X): the ping-pong 256x320 tile when N is a multiple of 320 and the
+// launch is at least ~1.5 rounds of 256 CUs (SAM ViT-H: N = 1280 / 3840 / 5120, where batch 8 gives exact round
+// counts and 10 % fewer staged bytes per flop than 256x256); else the 16-wave 256x256 tile whenever it fills the
+// chip (>= ~200 tiles) and N does not waste a large part of a 256-wide tile; else the 128x128 tile.
 extern "C" int ink_gemm_query_variant(int32_t M, int32_t N, int32_t K) {
   if (K % 64 != 0) return 32;      // 128x128x32 tile
+  if (N % 320 == 0 && K >= 128 && (long)((M + 255) / 256) * (N / 320) >= 384) return 45;
   const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   const bool n_fits = (N % 256 == 0) || N >= 1024;
   return (tiles256 >= 200 && n_fits) ? 10 : 0;
@@ -568,12 +605,15 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     case 8: return launch_gemm<256, 256, 32, 2, 4, 4>(p, s);     // 128 KB, 8 waves
     case 9: return launch_gemm<256, 256, 64, 4, 2, 2>(p, s);     // 8 waves x (64x128)
     case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s, gm);    // 16 waves x (64x64)
-    case 40: return launch_gemm_pp<4>(p, s, gm);       // ping-pong, ring of 4 x K32 granules (128 KB)
-    case 42: return launch_gemm_pp<3>(p, s, gm);       // ring of 3 (96 KB)
-    case 43: return launch_gemm_pp<4, 1>(p, s, gm);    // ablations / instrumentation, see the kernel comment
-    case 44: return launch_gemm_pp<4, 3>(p, s, gm);
-    case 46: return launch_gemm_pp<4, 7>(p, s, gm);
-    case 48: return launch_gemm_pp<4, 8>(p, s, gm);
+    case 40: return launch_gemm_pp<4>(p, s, gm);          // ping-pong 256x256, ring of 4 x K32 granules (128 KB)
+    case 42: return launch_gemm_pp<3>(p, s, gm);          // ring of 3 (96 KB)
+    case 45: return launch_gemm_pp<4, 5>(p, s, gm);       // ping-pong 256x320, ring of 4 (144 KB)
+    case 47: return launch_gemm_pp<3, 5>(p, s, gm);       // ring of 3 (108 KB)
+    case 43: return launch_gemm_pp<4, 4, 1>(p, s, gm);    // ablations / instrumentation, see the kernel comment
+    case 44: return launch_gemm_pp<4, 4, 3>(p, s, gm);
+    case 46: return launch_gemm_pp<4, 4, 7>(p, s, gm);
+    case 48: return launch_gemm_pp<4, 4, 8>(p, s, gm);
+    case 49: return launch_gemm_pp<4, 5, 8>(p, s, gm);
     case 21: return launch_gemm<256, 256, 64, 4, 4, 2, 1>(p, s, gm);  // ablation: no DMA after tile 1
     case 22: return launch_gemm<256, 256, 64, 4, 4, 2, 2>(p, s, gm);  // ablation: no MFMA
     case 23: return launch_gemm<256, 256, 64, 4, 4, 2, 3>(p, s, gm);  // ablation: no epilogue

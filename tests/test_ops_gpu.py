@@ -70,12 +70,12 @@ def test_gemm_epilogue_scatter_residual_scale_f16(dev):
     assert (o16.double() - ref2).abs().max().item() < 2e-3 * ref2.abs().max().item()
 
 
-@pytest.mark.parametrize("variant", [-1, 0, 10, 40, 42])
+@pytest.mark.parametrize("variant", [-1, 0, 10, 40, 42, 45, 47])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16])
 def test_gemm_residual_preload_rowmap(dev, variant, out_dtype):
     """Linear residual (no activation / layer scale) is preloaded into the accumulators before the K loop and the
     epilogue is load-free: check it with a scattering row_map that drops rows, ragged M/N tiles, K deep enough for
-    several K-tiles, on every tile family (auto, 128x128, 16-wave 256x256, ping-pong rings 4 and 3)."""
+    several K-tiles, on every tile family (auto, 128x128, 16-wave 256x256, ping-pong 256x256 and 256x320)."""
     from inklayer_amd import ops, _lib
     g = torch.Generator(device="cpu").manual_seed(11)
     M, N, K, R = 1100, 712, 320, 1000
