@@ -374,9 +374,12 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   const int grp = wave >> 2, wn = wave & 3;         // grp = wave row (128 rows each), wn = wave column (64 cols)
   const int fr = lane & 15, fq = lane >> 4;
 
-  unsigned wg_rt[4] = {0, 0, 0, 0};
+  unsigned wg_rt[4] = {0, 0, 0, 0}, wg_cy[4] = {0, 0, 0, 0};
   auto stamp_rt = [&](int k) {
-    if ((ABL & 8) && wave == 0) wg_rt[k] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    if ((ABL & 8) && wave == 0) {
+      wg_rt[k] = (unsigned)__builtin_amdgcn_s_memrealtime();
+      wg_cy[k] = (unsigned)__builtin_readcyclecounter();
+    }
   };
   stamp_rt(0);
   const float* dbg_out = p.residual;
@@ -523,21 +526,23 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
       out[0] = __builtin_amdgcn_s_getreg(63492);    // HW_ID
       out[1] = __builtin_amdgcn_s_getreg(6164);     // XCC_ID
       out[2] = wg_rt[0]; out[3] = wg_rt[1]; out[4] = wg_rt[2]; out[5] = wg_rt[3];
+      out[6] = wg_cy[2] - wg_cy[1];                 // shader cycles of the main loop
+      out[7] = wg_cy[3] - wg_cy[2];                 // ... of the epilogue
     }
   }
 }
 
-template <int RING, int TN = 4, int ABL = 0>
+template <int RING, int TN = 4, int ABL = 0, bool LATE_A = (TN > 4)>
 static int launch_gemm_pp(const InkGemm& p, hipStream_t s, int group_m) {
   if (p.K / 32 < RING) return 1;
   constexpr int BN = 64 * TN;
   constexpr int lds = RING * (256 + BN) * 32 * 2;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt_pp<RING, TN, ABL>,
+  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt_pp<RING, TN, ABL, LATE_A>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)attr;
   const int ntiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_f16_nt_pp<RING, TN, ABL>), dim3(ntiles), dim3(512), lds, s, p, group_m);
+  hipLaunchKernelGGL((gemm_f16_nt_pp<RING, TN, ABL, LATE_A>), dim3(ntiles), dim3(512), lds, s, p, group_m);
   return ink_launch_status();
 }
 
@@ -594,36 +599,31 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     v = ink_gemm_query_variant(p.M, p.N, p.K);
     gm = 4;
   }
+  // Production variants: 0 / 32 (128x128 tiles, K step 64 / 32), 10 (16-wave 256x256), 45 (ping-pong 256x320).
+  // The rest are the alternatives and the ablation / instrumentation builds DESIGN.md's measurements come from;
+  // they are only reachable through ink_gemm_set_variant / INK_GEMM_VARIANT (tools/gemm_sweep.py, gemm_stamps.py).
   switch (v) {
-    case 1: return launch_gemm<128, 128, 64, 2, 2, 4>(p, s);     // 128 KB, 1 block/CU, 3 tiles in flight
-    case 2: return launch_gemm<256, 128, 64, 4, 2, 3>(p, s);     // 144 KB, 8 waves, 2 tiles in flight
-    case 3: return launch_gemm<128, 128, 32, 2, 2, 4>(p, s);     // 64 KB, 2 blocks/CU, 3 half-tiles in flight
-    case 4: return launch_gemm<256, 256, 64, 2, 4, 2>(p, s);     // 128 KB, 8 waves x (128x64)
-    case 5: return launch_gemm<128, 128, 64, 2, 2, 3>(p, s);     // 96 KB, 1 block/CU, 2 tiles in flight
-    case 6: return launch_gemm<256, 128, 32, 4, 2, 5>(p, s);     // 120 KB, 8 waves, 4 half-tiles in flight
-    case 7: return launch_gemm<256, 256, 32, 2, 4, 3>(p, s);     // 96 KB, 8 waves
-    case 8: return launch_gemm<256, 256, 32, 2, 4, 4>(p, s);     // 128 KB, 8 waves
-    case 9: return launch_gemm<256, 256, 64, 4, 2, 2>(p, s);     // 8 waves x (64x128)
-    case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s, gm);    // 16 waves x (64x64)
-    case 40: return launch_gemm_pp<4>(p, s, gm);          // ping-pong 256x256, ring of 4 x K32 granules (128 KB)
-    case 42: return launch_gemm_pp<3>(p, s, gm);          // ring of 3 (96 KB)
-    case 45: return launch_gemm_pp<4, 5>(p, s, gm);       // ping-pong 256x320, ring of 4 (144 KB)
-    case 47: return launch_gemm_pp<3, 5>(p, s, gm);       // ring of 3 (108 KB)
-    case 43: return launch_gemm_pp<4, 4, 1>(p, s, gm);    // ablations / instrumentation, see the kernel comment
+    case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s, gm);       // 16 waves x (64x64), 2 x 64 KB stages
+    case 45: return launch_gemm_pp<4, 5>(p, s, gm);                     // ping-pong 256x320, ring of 4 (144 KB)
+    case 40: return launch_gemm_pp<4>(p, s, gm);                        // ping-pong 256x256, ring of 4 (128 KB)
+    case 42: return launch_gemm_pp<3>(p, s, gm);                        // ... ring of 3 (96 KB)
+    case 47: return launch_gemm_pp<3, 5>(p, s, gm);                     // 256x320, ring of 3 (DMA 1 granule ahead)
+    case 53: return launch_gemm_pp<4, 5, 0, false>(p, s, gm);           // 256x320, 8 A fragments live, 3 ahead
+    case 16: return launch_gemm<128, 128, 64, 2, 2, 2>(p, s, gm);       // variant 0 with grouped tile order
+    case 12: return launch_gemm<128, 256, 64, 2, 4, 2>(p, s);           // 8 waves x (64x64), 96 KB
+    case 14: return launch_gemm<256, 128, 32, 4, 2, 2>(p, s, gm);       // 48 KB: 3 workgroups / CU
+    case 11: return launch_gemm<256, 256, 32, 4, 4, 4>(p, s);           // 16 waves, counted-vmcnt ring of 4 x K32
+    case 21: return launch_gemm<256, 256, 64, 4, 4, 2, 1>(p, s, gm);    // variant 10 ablations: no DMA after tile 1
+    case 22: return launch_gemm<256, 256, 64, 4, 4, 2, 2>(p, s, gm);    // ... no MFMA
+    case 23: return launch_gemm<256, 256, 64, 4, 4, 2, 3>(p, s, gm);    // ... no epilogue
+    case 43: return launch_gemm_pp<4, 4, 1>(p, s, gm);                  // ping-pong ablations (see the kernel comment)
     case 44: return launch_gemm_pp<4, 4, 3>(p, s, gm);
     case 46: return launch_gemm_pp<4, 4, 7>(p, s, gm);
-    case 48: return launch_gemm_pp<4, 4, 8>(p, s, gm);
-    case 49: return launch_gemm_pp<4, 5, 8>(p, s, gm);
-    case 21: return launch_gemm<256, 256, 64, 4, 4, 2, 1>(p, s, gm);  // ablation: no DMA after tile 1
-    case 22: return launch_gemm<256, 256, 64, 4, 4, 2, 2>(p, s, gm);  // ablation: no MFMA
-    case 23: return launch_gemm<256, 256, 64, 4, 4, 2, 3>(p, s, gm);  // ablation: no epilogue
-    case 11: return launch_gemm<256, 256, 32, 4, 4, 4>(p, s);    // 16 waves, 3 half-tiles in flight
-    case 14: return launch_gemm<256, 128, 32, 4, 2, 2>(p, s, gm);    // 48 KB: 2-3 blocks/CU, 8 waves x (64x64)
-    case 15: return launch_gemm<128, 256, 32, 2, 4, 2>(p, s, gm);
-    case 16: return launch_gemm<128, 128, 64, 2, 2, 2>(p, s, gm);    // v0 with grouping
-    case 17: return launch_gemm<256, 128, 32, 4, 2, 3>(p, s, gm);    // 72 KB: 2 blocks/CU, 2 half-tiles in flight
-    case 12: return launch_gemm<128, 256, 64, 2, 4, 2>(p, s);    // 8 waves x (64x64), 96 KB
-    case 13: return launch_gemm<256, 128, 64, 4, 2, 2>(p, s);    // 8 waves x (64x64), 96 KB
-    default: return launch_gemm<128, 128, 64, 2, 2, 2>(p, s);    // round-1 kernel
+    case 48: return launch_gemm_pp<4, 4, 8>(p, s, gm);                  // per-workgroup timeline, 256x256
+    case 49: return launch_gemm_pp<4, 5, 8>(p, s, gm);                  // ... 256x320
+    case 50: return launch_gemm_pp<4, 5, 9>(p, s, gm);                  // ... without MFMA
+    case 51: return launch_gemm_pp<4, 5, 11>(p, s, gm);                 // ... pure DMA stream
+    case 52: return launch_gemm_pp<4, 5, 15>(p, s, gm);                 // ... pure DMA stream, all L2 hits
+    default: return launch_gemm<128, 128, 64, 2, 2, 2>(p, s);           // variant 0
   }
 }

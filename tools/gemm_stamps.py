@@ -11,7 +11,7 @@ m, n, k = 32768, 3840, 1280
 a = torch.randn(m, k, device=dev).half(); w = (torch.randn(n, k, device=dev) * 0.05).half()
 out = torch.empty(m, n, device=dev, dtype=torch.float16)
 for v in [int(x) for x in sys.argv[1:] if x.isdigit()] or [448]:
-    ntiles = (m // 256) * (n // (320 if v % 100 == 49 else 256))
+    ntiles = (m // 256) * (n // (320 if v % 100 in (49, 50, 51, 52, 54) else 256))
     dbg = torch.zeros(m, n, device=dev, dtype=torch.float32)       # stands in for `residual`
     _lib.lib().ink_gemm_set_variant(v)
     for _ in range(3):
@@ -27,6 +27,9 @@ for v in [int(x) for x in sys.argv[1:] if x.isdigit()] or [448]:
     print(f"  fill     mean {float((fil - ent).float().mean()) / 1000:6.2f} us   (p10 {float((fil - ent).float().quantile(0.1)) / 1000:.2f}, p90 {float((fil - ent).float().quantile(0.9)) / 1000:.2f})")
     print(f"  loop     mean {float((lo - fil).float().mean()) / 1000:6.2f} us   (p10 {float((lo - fil).float().quantile(0.1)) / 1000:.2f}, p90 {float((lo - fil).float().quantile(0.9)) / 1000:.2f})")
     print(f"  epilogue mean {float((st - lo).float().mean()) / 1000:6.2f} us   (p10 {float((st - lo).float().quantile(0.1)) / 1000:.2f}, p90 {float((st - lo).float().quantile(0.9)) / 1000:.2f})")
+    ghz_loop = (t[:, 6].float() / (lo - fil).float().clamp(min=1)).mean()
+    ghz_epi = (t[:, 7].float() / (st - lo).float().clamp(min=1)).mean()
+    print(f"  shader clock: {float(ghz_loop):.2f} GHz during the main loop, {float(ghz_epi):.2f} GHz during the epilogue")
     gaps = []
     for kk in key.unique().tolist():
         idx = (key == kk).nonzero().flatten()
@@ -38,12 +41,4 @@ for v in [int(x) for x in sys.argv[1:] if x.isdigit()] or [448]:
     kk = key.unique().tolist()[0]
     idx = (key == kk).nonzero().flatten(); order = idx[ent[idx].argsort()]
     print("  one CU:", " | ".join(f"{int(ent[i])/1000:.1f}+{int(fil[i]-ent[i])/1000:.1f}+{int(lo[i]-fil[i])/1000:.1f}+{int(st[i]-lo[i])/1000:.1f}" for i in order))
-    if v == 454:
-        e = dbg.view(torch.int32).flatten()[65536:65536 + 1024].cpu().view(2, 64, 8).long() & 0xffffffff
-        for g in range(2):
-            print(f"  group {g} epilogue slabs (cycles): [bias/act + LDS write | (stamp) | LDS read + store issue]")
-            for ti in range(8):
-                r = e[g, 40 + ti]
-                nxt = e[g, 41 + ti, 0] if ti < 7 else r[2]
-                print(f"    slab {ti}: {int((r[1]-r[0]) % 2**32):6d} {int((r[2]-r[1]) % 2**32):6d}   to next slab {int((nxt-r[2]) % 2**32):6d}")
 _lib.lib().ink_gemm_set_variant(-1)

@@ -3,6 +3,7 @@ usage: prof_summary.py <rocprof_dir> <out_json>"""
 import collections, csv, glob, json, sys
 
 def bucket(name):
+    if "gemm_f16_nt_pp<4, 5" in name: return "gemm_pp320"
     if "gemm_f16_nt<256, 256, 64, 4, 4, 2" in name: return "gemm256"
     if "gemm_f16_nt" in name: return "gemm_other"
     if "flash_attn_kernel<80, 1" in name: return "attn_global"
