@@ -16,6 +16,7 @@
 //                   INIT (no per-score VALU work).
 //   2 "augmented" : 14x14 windows; the bias rides in the MFMA: Q' = [q | rel(q,.)/scale],
 //                   K' = [k | onehot(kh), onehot(kw)] (two extra 16-wide k-steps).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/inklayer_hip.h"
 
@@ -64,31 +65,143 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, hh = lane >> 5;
   const int nqb = (p.n_q + NW * 32 - 1) / (NW * 32);
-  const int bh = blockIdx.x / nqb, qb = blockIdx.x % nqb;
-  const int b = bh / p.n_heads, h = bh % p.n_heads;
-  const int q_idx = qb * NW * 32 + wave * 32 + lq;
-  bool q_ok = q_idx < p.n_q;
-  const int q_c = q_ok ? q_idx : p.n_q - 1;
+  // ALLKV (SAM windows) is PERSISTENT: workgroup w walks blocks [w*total/G, (w+1)*total/G) - consecutive heads of
+  // the same few windows - and loads the K/V rows and the Q / rel-pos fragments of block i+1 into registers while
+  // it computes block i, so the load -> barrier -> compute -> store chain of a (window, head) no longer runs
+  // serially at one workgroup per CU.  Everything else: one block per workgroup.
+  const int total = p.n_batch * p.n_heads * nqb;
+  int blk = ALLKV ? (int)((int64_t)blockIdx.x * total / gridDim.x) : (int)blockIdx.x;
+  const int blk_end = ALLKV ? (int)((int64_t)(blockIdx.x + 1) * total / gridDim.x) : blk + 1;
 
-  // ---- Q^T fragments (B operand): lane (col = q, half hh) holds Q[q][16 s + 8 hh + j]
-  const int64_t qrow0 = p.q_batch_rows ? (int64_t)p.q_batch_rows[b] : (int64_t)b * p.n_q;
-  int64_t q_row = qrow0 + q_c;                     // row of this query in Q (and, with tok_rows, in O)
-  if constexpr (MODE == 2 && ALLKV) {
-    if (p.tok_rows) {
-      const int r = p.tok_rows[(int64_t)b * p.n_q + q_c];
-      q_ok = q_ok && r >= 0;                       // window padding: nothing to compute, nothing to store
-      q_row = r >= 0 ? r : 0;
+  // Q^T fragments (B operand): lane (col = q, half hh) holds Q[q][16 s + 8 hh + j]; + the rel-pos columns (mode 2)
+  struct QState { bool ok; int64_t row; };
+  // ALLKV + tok_rows: the token rows of a window depend on the window only, not on the head, and a workgroup walks
+  // consecutive heads of the same window, so they are cached in registers (wrow_q, wrow_k) and re-read only when
+  // the window changes - the prefetch of the next block then has no dependent load in it
+  constexpr int KALL = ALLKV ? (MAXT * 64 * CH + NT - 1) / NT : 1;
+  int wrow_q = 0, wrow_k[KALL], wrow_b = -1;
+  auto load_wrows = [&](int b_) {
+    if (MODE == 2 && ALLKV && p.tok_rows && b_ != wrow_b) {
+      const int qi = wave * 32 + lq;
+      wrow_q = p.tok_rows[(int64_t)b_ * p.n_q + (qi < p.n_q ? qi : p.n_q - 1)];
+#pragma unroll
+      for (int it = 0; it < KALL; ++it) {
+        const int key = (tid + it * NT) / CH;
+        wrow_k[it] = key < p.n_k ? p.tok_rows[(int64_t)b_ * p.n_k + key] : -1;
+      }
+      wrow_b = b_;
+    }
+  };
+  auto load_q = [&](int blk_, f16x8 (&dst)[NQK]) -> QState {
+    const int bh_ = blk_ / nqb, qb_ = blk_ % nqb;
+    const int b_ = bh_ / p.n_heads, h_ = bh_ % p.n_heads;
+    const int qi = qb_ * NW * 32 + wave * 32 + lq;
+    bool ok = qi < p.n_q;
+    const int qc = ok ? qi : p.n_q - 1;
+    const int64_t qrow0 = p.q_batch_rows ? (int64_t)p.q_batch_rows[b_] : (int64_t)b_ * p.n_q;
+    int64_t row = qrow0 + qc;                      // row of this query in Q (and, with tok_rows, in O)
+    if constexpr (MODE == 2 && ALLKV) {
+      if (p.tok_rows) {
+        ok = ok && wrow_q >= 0;                    // window padding: nothing to compute, nothing to store
+        row = wrow_q >= 0 ? wrow_q : 0;
+      }
+    }
+    const f16* Qrow = (const f16*)p.Q + row * p.ldq + h_ * HD;
+#pragma unroll
+    for (int s = 0; s < NQKB; ++s) dst[s] = *(const f16x8*)(Qrow + 16 * s + 8 * hh);
+    if constexpr (MODE == 2) {
+      const f16* R = (const f16*)p.rel_aug + ((int64_t)bh_ * p.n_q + qc) * 32;
+      dst[NQKB] = *(const f16x8*)(R + 8 * hh);
+      dst[NQKB + 1] = *(const f16x8*)(R + 16 + 8 * hh);
+    }
+    return QState{ok, row};
+  };
+  // all K/V rows of a (batch, head) into registers (ALLKV): tok_rows gathers them, padded keys take qkv(0)
+  f16x8 ka[KALL], va[KALL];
+  (void)ka; (void)va;
+  auto load_kv_all = [&](int blk_) {
+    const int bh_ = blk_ / nqb;
+    const int b_ = bh_ / p.n_heads, h_ = bh_ % p.n_heads;
+    const int64_t kvb_ = p.kv_batch_rows ? (int64_t)p.kv_batch_rows[b_] : (int64_t)b_ * p.n_k;
+#pragma unroll
+    for (int it = 0; it < KALL; ++it) {
+      const int ci = tid + it * NT;
+      const int key = ci / CH, cc = ci % CH;
+      ka[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      va[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (ci < MAXT * 64 * CH && key < p.n_k) {
+        int64_t r = kvb_ + key;
+        if (MODE == 2 && p.tok_rows) r = wrow_k[it];
+        if (r >= 0) {
+          ka[it] = *(const f16x8*)((const f16*)p.K + r * p.ldk + h_ * HD + cc * 8);
+          va[it] = *(const f16x8*)((const f16*)p.V + r * p.ldv + h_ * HD + cc * 8);
+        } else {                                   // padded key: qkv(0) = the bias rows
+          ka[it] = *(const f16x8*)((const f16*)p.pad_k + h_ * HD + cc * 8);
+          va[it] = *(const f16x8*)((const f16*)p.pad_v + h_ * HD + cc * 8);
+        }
+      }
+    }
+  };
+  load_wrows((blk / nqb) / p.n_heads);
+  f16x8 qf[NQK];
+  QState qs = load_q(blk, qf);
+  if constexpr (ALLKV) load_kv_all(blk);
+  // V pad columns: zero, except a ones-column (d = HD for the lower half-wave, HD+4 for the upper) so that the
+  // PV MFMA also yields l = sum_k P[q,k] in o[NB-1][..] of BOTH halves
+  if constexpr (DVP > HD) {
+    constexpr int PCH = (DVP - HD) / 8;
+    for (int i = tid; i < MAXT * 64 * PCH; i += NT) {
+      const int row = (i / PCH) % 64, pc = i % PCH, tl = i / (64 * PCH);
+      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (LSUM_MFMA && pc == 0) { z[0] = (f16)1; z[4] = (f16)1; }
+      *(f16x8*)(sV + tl * TILEB + row * VROW + (CH + pc) * 16) = z;
     }
   }
-  const f16* Qrow = (const f16*)p.Q + q_row * p.ldq + h * HD;
-  f16x8 qf[NQK];
+  // per-thread byte offsets of its K/V chunks inside a 64-key tile (32-bit; the tile base is wave-uniform)
+  int koff_g[KIT], voff_g[KIT], loff_k[KIT], loff_v[KIT];
 #pragma unroll
-  for (int s = 0; s < NQKB; ++s) qf[s] = *(const f16x8*)(Qrow + 16 * s + 8 * hh);
-  if constexpr (MODE == 2) {
-    const f16* R = (const f16*)p.rel_aug + ((int64_t)bh * p.n_q + q_c) * 32;
-    qf[NQKB] = *(const f16x8*)(R + 8 * hh);
-    qf[NQKB + 1] = *(const f16x8*)(R + 16 + 8 * hh);
+  for (int it = 0; it < KIT; ++it) {
+    const int ci = tid + it * NT;
+    const int row = (ci / CH) & 63, cc = ci % CH;
+    koff_g[it] = (row * (int)p.ldk + cc * 8) * 2;
+    voff_g[it] = (row * (int)p.ldv + cc * 8) * 2;
+    loff_k[it] = row * KROW + cc * 16;
+    loff_v[it] = row * VROW + cc * 16;
   }
+  if constexpr (MODE == 2 && ALLKV) {   // one-hot (kh, kw) columns of K': the same for every block, written once
+    for (int i = tid; i < MAXT * 256; i += NT) {
+      const int key = i >> 2, c4 = i & 3;
+      const int kh = key / p.grid_w, kw = key - kh * p.grid_w + p.grid_w;
+      f16x8 e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int col = c4 * 8 + j;
+        e[j] = (key < p.n_k && (col == kh || col == kw)) ? (f16)1 : (f16)0;
+      }
+      *(f16x8*)(sK + (key >> 6) * TILEB + (key & 63) * KROW + (CH + c4) * 16) = e;
+    }
+  }
+  const float c = p.scale * 1.44269504088896340736f;
+  const int ntiles = (p.n_k + 63) / 64;
+  // the last tile of a 14x14 window holds 4 of its 64 key slots: only its first 32-key half is computed
+  const bool half_tail = ALLKV && (p.n_k - (ntiles - 1) * 64) <= 32;
+  // per-lane LDS read offsets
+  const int koff0 = lq * KROW + hh * 16;
+  const int koff1 = (32 + lq) * KROW + hh * 16;
+  const int voff = (4 * hh + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  // register index / half that holds row d = HD (+4 for hh = 1) of O^T
+  constexpr int LI = HD / 32, LR = (((HD % 32) / 8) * 4);
+
+  for (; blk < blk_end; ++blk) {
+  const int bh = blk / nqb, qb = blk % nqb;
+  const int b = bh / p.n_heads, h = bh % p.n_heads;
+  const int q_idx = qb * NW * 32 + wave * 32 + lq;
+  const int q_c = q_idx < p.n_q ? q_idx : p.n_q - 1;
+  const bool q_ok = qs.ok;
+  const int64_t q_row = qs.row;
+  const int64_t kvb = p.kv_batch_rows ? (int64_t)p.kv_batch_rows[b] : (int64_t)b * p.n_k;
+  const char* Kb = (const char*)((const f16*)p.K + kvb * p.ldk + h * HD);
+  const char* Vb = (const char*)((const f16*)p.V + kvb * p.ldv + h * HD);
   float bias3[2][16];   // mode 3 only: the whole (bias + mask) row of this query (single tile)
   const float* RH = nullptr;
   if constexpr (MODE == 3) {
@@ -117,34 +230,6 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
     }
   }
 
-  // V pad columns: zero, except a ones-column (d = HD for the lower half-wave, HD+4 for the upper) so that the
-  // PV MFMA also yields l = sum_k P[q,k] in o[NB-1][..] of BOTH halves
-  if constexpr (DVP > HD) {
-    constexpr int PCH = (DVP - HD) / 8;
-    for (int i = tid; i < MAXT * 64 * PCH; i += NT) {
-      const int row = (i / PCH) % 64, pc = i % PCH, tl = i / (64 * PCH);
-      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (LSUM_MFMA && pc == 0) { z[0] = (f16)1; z[4] = (f16)1; }
-      *(f16x8*)(sV + tl * TILEB + row * VROW + (CH + pc) * 16) = z;
-    }
-  }
-  // register index / half that holds row d = HD (+4 for hh = 1) of O^T
-  constexpr int LI = HD / 32, LR = (((HD % 32) / 8) * 4);
-
-  const int64_t kvb = p.kv_batch_rows ? (int64_t)p.kv_batch_rows[b] : (int64_t)b * p.n_k;
-  const char* Kb = (const char*)((const f16*)p.K + kvb * p.ldk + h * HD);
-  const char* Vb = (const char*)((const f16*)p.V + kvb * p.ldv + h * HD);
-  // per-thread byte offsets of its K/V chunks inside a 64-key tile (32-bit; the tile base is wave-uniform)
-  int koff_g[KIT], voff_g[KIT], loff_k[KIT], loff_v[KIT];
-#pragma unroll
-  for (int it = 0; it < KIT; ++it) {
-    const int ci = tid + it * NT;
-    const int row = (ci / CH) & 63, cc = ci % CH;
-    koff_g[it] = (row * (int)p.ldk + cc * 8) * 2;
-    voff_g[it] = (row * (int)p.ldv + cc * 8) * 2;
-    loff_k[it] = row * KROW + cc * 16;
-    loff_v[it] = row * VROW + cc * 16;
-  }
   f16x8 kreg[KIT], vreg[KIT];
   auto load_tile = [&](int t) {
     const char* kt = Kb + (int64_t)t * 64 * p.ldk * 2;
@@ -193,57 +278,14 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = NEG, l_run = 0.f;
-  const float c = p.scale * 1.44269504088896340736f;
-  const int ntiles = (p.n_k + 63) / 64;
-
-  // per-lane LDS read offsets
-  const int koff0 = lq * KROW + hh * 16;
-  const int koff1 = (32 + lq) * KROW + hh * 16;
-  const int voff = (4 * hh + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
   float rh_next = 0.f;
   if constexpr (MODE == 1) rh_next = RH[0];
   if constexpr (ALLKV) {
-    // all K/V rows of this (batch, head) at once: every global load is issued back-to-back, ONE barrier,
-    // then the tile loop runs without any synchronisation (14x14 windows: 196 keys = 4 tiles).
-    constexpr int KALL = (MAXT * 64 * CH + NT - 1) / NT;
-    f16x8 ka[KALL], va[KALL];
-#pragma unroll
-    for (int it = 0; it < KALL; ++it) {
-      const int ci = tid + it * NT;
-      const int key = ci / CH, cc = ci % CH;
-      if (ci < MAXT * 64 * CH && key < p.n_k) {
-        if (MODE == 2 && p.tok_rows) {
-          const int r = p.tok_rows[(int64_t)b * p.n_k + key];
-          if (r >= 0) {
-            ka[it] = *(const f16x8*)((const f16*)p.K + (int64_t)r * p.ldk + h * HD + cc * 8);
-            va[it] = *(const f16x8*)((const f16*)p.V + (int64_t)r * p.ldv + h * HD + cc * 8);
-          } else {                                 // padded key: qkv(0) = the bias rows
-            ka[it] = *(const f16x8*)((const f16*)p.pad_k + h * HD + cc * 8);
-            va[it] = *(const f16x8*)((const f16*)p.pad_v + h * HD + cc * 8);
-          }
-        } else {
-          ka[it] = *(const f16x8*)(Kb + ((int64_t)key * p.ldk + cc * 8) * 2);
-          va[it] = *(const f16x8*)(Vb + ((int64_t)key * p.ldv + cc * 8) * 2);
-        }
-      } else {
-        ka[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        va[it] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      }
-    }
-    if constexpr (MODE == 2) {
-      for (int i = tid; i < MAXT * 256; i += NT) {
-        const int key = i >> 2, c4 = i & 3;
-        const int kh = key / p.grid_w, kw = key - kh * p.grid_w + p.grid_w;
-        f16x8 e;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int col = c4 * 8 + j;
-          e[j] = (key < p.n_k && (col == kh || col == kw)) ? (f16)1 : (f16)0;
-        }
-        *(f16x8*)(sK + (key >> 6) * TILEB + (key & 63) * KROW + (CH + c4) * 16) = e;
-      }
-    }
+    // the rows of this block are in ka/va (issued one block ago): hand them to LDS between two barriers (the first
+    // one: every wave has finished reading the previous block's tiles), then immediately issue the loads of the
+    // next block so that they fly during the tile loop, which runs without any synchronisation
+    __syncthreads();
 #pragma unroll
     for (int it = 0; it < KALL; ++it) {
       const int ci = tid + it * NT;
@@ -254,10 +296,16 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
       }
     }
     __syncthreads();
+    if (blk + 1 < blk_end) {
+      load_wrows(((blk + 1) / nqb) / p.n_heads);   // a (rare) window change costs one exposed round trip
+      load_kv_all(blk + 1);
+    }
   } else {
     load_tile(0);
   }
-  for (int t = 0; t < ntiles; ++t) {
+  // (a wave whose 32 queries are all window padding - bottom-row windows - has nothing to compute)
+  const int nt_wave = (ALLKV && !__any(q_ok)) ? 0 : ntiles;
+  for (int t = 0; t < nt_wave; ++t) {
     if constexpr (!ALLKV) {
       __syncthreads();  // previous tile fully consumed
       store_tile(t);
@@ -287,12 +335,21 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
     }
+    const bool half = half_tail && t == ntiles - 1;     // wave-uniform: keys 32..63 of this tile do not exist
+    if (half) {
 #pragma unroll
-    for (int s = (MODE == 1 ? 1 : 0); s < NQK; ++s) {
-      const f16x8 k0 = *(const f16x8*)(tK + koff0 + s * 32);
-      const f16x8 k1 = *(const f16x8*)(tK + koff1 + s * 32);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+      for (int s = 0; s < NQK; ++s) {
+        const f16x8 k0 = *(const f16x8*)(tK + koff0 + s * 32);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = (MODE == 1 ? 1 : 0); s < NQK; ++s) {
+        const f16x8 k0 = *(const f16x8*)(tK + koff0 + s * 32);
+        const f16x8 k1 = *(const f16x8*)(tK + koff1 + s * 32);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+      }
     }
     if ((t + 1) * 64 > p.n_k) {  // ragged last tile: mask keys >= n_k (wave-uniform branch)
 #pragma unroll
@@ -344,6 +401,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
     pf[3] = cvt8(s1, 8);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      if (ks >= 2 && half) break;                        // P of keys 32..63 is exactly 0 there
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const char* base = tV + voff + (16 * ks) * VROW + i * 64;
@@ -378,6 +436,10 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
         }
       }
   }
+  if constexpr (ALLKV) {
+    if (blk + 1 < blk_end) qs = load_q(blk + 1, qf);   // flies during the barriers / LDS hand-off of the next block
+  }
+  }   // block loop
 }
 
 // Decomposed relative-position terms, pre-divided by the softmax scale so that they can sit
@@ -566,6 +628,13 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
   INK_CHECK_ARG((((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) == 0);
   INK_CHECK_ARG(((uintptr_t)p.O & 7) == 0);
   INK_CHECK_ARG(!p.tok_rows || p.bias_mode == 2);
+  static const int n_cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  // INK_ATTN_PERSIST=0: one (window, head) per workgroup instead of the persistent walk (A/B measurements only)
+  static const bool persist = !(getenv("INK_ATTN_PERSIST") && atoi(getenv("INK_ATTN_PERSIST")) == 0);
   hipStream_t s = (hipStream_t)stream;
   const int bhn = p.n_batch * p.n_heads;
 #define INK_FA_X(HD, MODE, NW, ALL)                                                                      \
@@ -577,7 +646,8 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_), true); \
     (void)attr_;                                                                                           \
     const int nqb = (p.n_q + NW * 32 - 1) / (NW * 32);                                                     \
-    hipLaunchKernelGGL((flash_attn_kernel<HD, MODE, NW, ALL>), dim3(bhn * nqb), dim3(NW * 64), lds_, s, p); \
+    const int grid_ = (ALL && persist) ? (bhn * nqb < n_cus ? bhn * nqb : n_cus) : bhn * nqb;                \
+    hipLaunchKernelGGL((flash_attn_kernel<HD, MODE, NW, ALL>), dim3(grid_), dim3(NW * 64), lds_, s, p);      \
   }
 #define INK_FA(HD, MODE, NW) INK_FA_X(HD, MODE, NW, false)
   if (p.head_dim == 80 && p.bias_mode == 1) {
