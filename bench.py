@@ -4,10 +4,10 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A step = one pass of the hot path over one batch of B synthetic 1024x1024 sketches per GPU
-(BASELINE.json config "Full GroundingDINO Swin-T + SAM ViT-H pipeline, batch=8, 1 MI355X"): detector
-forward (B images) -> host threshold/box glue (top-16 boxes per image so the work does not depend on the
+(BASELINE.json config "Full GroundingDINO Swin-T + SAM ViT-H pipeline, batch=8, 1 MI355X"): the two
+Pillow-exact resizes on the GPU -> detector forward (B images) -> host threshold/box glue (top-16 boxes per image so the work does not depend on the
 random weights) -> SAM encoder (B images) -> prompt encoder + mask decoder + postprocess
-(16 boxes per image) -> B x 16 bool masks at 1024x1024.  The resized uint8 images are resident in HBM
+(16 boxes per image) -> B x 16 bool masks at 1024x1024.  The decoded uint8 sketches are resident in HBM
 when the timed region starts; masks stay on the GPU, boxes/scores cross to the host (they steer the
 control flow).  Image-parallel over ranks (weak scaling), one RCCL weight broadcast at start-up, no
 per-batch collectives.  Prints ONE JSON line on rank 0.
@@ -153,17 +153,17 @@ def main():
     B = args.batch
     # rank r owns global images r, r+world, ... (static round-robin shard); synthetic, seeded per image
     imgs = [synthetic.synthetic_sketch(i) for i in idist.shard_indices(B * world, rank, world)]
-    det_in, sam_in, sizes = pipe.prepare(imgs)
+    raw = pipe.upload(imgs)      # decoded RGB u8 sketches resident in HBM; both resizes run inside the timed step
     torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        pipe.run_prepared(det_in, sam_in, sizes, top_n=args.boxes)
+        pipe.run_uploaded(raw, top_n=args.boxes)
     torch.cuda.synchronize()
     idist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         # (defer_sync=True would also pipeline consecutive batches; measured slower: the GPU is already saturated)
-        res = pipe.run_prepared(det_in, sam_in, sizes, top_n=args.boxes)
+        res = pipe.run_uploaded(raw, top_n=args.boxes)
     torch.cuda.synchronize()
     idist.barrier()
     dt = time.perf_counter() - t0
@@ -177,7 +177,7 @@ def main():
         serial = pipeline.InkLayerPipeline(det, seg, overlap=False)
         ops.set_gemm_trace(trace)
         for _ in range(roof_steps):
-            serial.run_prepared(det_in, sam_in, sizes, top_n=args.boxes)
+            serial.run_uploaded(raw, top_n=args.boxes)
         torch.cuda.synchronize()
         ops.set_gemm_trace(None)
     assert len(res) == B and res[0].masks.shape == (args.boxes, 1024, 1024)

@@ -156,6 +156,19 @@ int ink_sam_patchify(const void* image_u8, int32_t h, int32_t w, int32_t L, int3
                      const float* mean3, const float* std3, int32_t chan_reverse, void* out_f16,
                      void* stream);
 
+/* Pillow's antialiased bilinear resize of an HWC uint8 RGB image, bit for bit: the `F.resize` of
+ * load_image (GD/util/inference.py:39-50, GD/datasets/transforms.py:87-117: shorter side 800, max 1333) and
+ * ResizeLongestSide.apply_image (SA/utils/transforms.py:26-31, 93-102), both of which end in PIL
+ * Image.resize(BILINEAR).  src [h, w, 3] -> dst [oh, ow, 3].  xbounds/ybounds: int32 [ow|oh, 2] = (first
+ * input sample, number of samples); xcoef/ycoef: int32 [ow|oh, kx|ky] 22-bit fixed-point weights, both
+ * exactly as Pillow's precompute_coeffs + normalize_coeffs_8bpc produce them (inklayer_amd/resize.py).
+ * Horizontal pass first, rounded to u8 into tmp [h, ow, 3] (needed only when both sizes change), then
+ * the vertical pass.  At least one of the two sizes must differ. */
+int ink_resize_bilinear_u8(const void* src_u8, int32_t h, int32_t w, void* dst_u8, int32_t oh, int32_t ow,
+                           const int32_t* xbounds, const int32_t* xcoef, int32_t kx,
+                           const int32_t* ybounds, const int32_t* ycoef, int32_t ky, void* tmp_u8,
+                           void* stream);
+
 /* 3x3 / pad-1 im2col of an NHWC f16 map [B,H,W,C] -> [B*H*W, 9*C] with column (ky*3+kx)*C + c
  * (neck conv SA/modeling/image_encoder.py:96-103; GD input_proj 3x3 s2 uses the strided form). */
 int ink_im2col3x3_f16(const void* in_f16, int32_t B, int32_t H, int32_t W, int32_t C, void* out_f16,

@@ -52,6 +52,8 @@ SIGNATURES = {
     "ink_sam_patchify": [c_void_p, c_int, c_int, c_int, c_int, C.POINTER(c_float), C.POINTER(c_float),
                          c_int, c_void_p, c_void_p],
     "ink_im2col3x3_f16": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ink_resize_bilinear_u8": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
+                               c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "ink_sam_pe_encode": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "ink_sam_mask_logits": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ink_sam_postprocess": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,

@@ -446,82 +446,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
 // next to q.k inside the accumulator:  rel_x[q, j] = (q . R_x[q_x - j + S - 1]) / scale.
 // SA/modeling/image_encoder.py:292-361.
 //
-// Work split so that the table row is WAVE-UNIFORM (scalar loads, SGPR operand of v_fma):
-// a wave handles the queries that share one grid coordinate f on the axis being processed
-// (axis 0: q_h == f, lanes run over q_w and batch*head; axis 1: q_w == f, lanes over q_h),
-// so every lane needs the same rows R[f - j + S - 1], j = 0..S-1.
-template <int HD, int S, bool AUG>
-__global__ __launch_bounds__(256) void relpos_kernel(const f16* __restrict__ Q, int64_t ldq,
-                                                     const float* __restrict__ Rh,
-                                                     const float* __restrict__ Rw, int n_batch,
-                                                     int n_heads, float inv_scale,
-                                                     float* __restrict__ out_h,
-                                                     float* __restrict__ out_w,
-                                                     f16* __restrict__ out_aug) {
-  constexpr int GPW = 64 / S;                   // (batch,head) groups per wave: 1 (S=64) or 4 (S=14)
-  constexpr int NQ = S * S;
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));  // wave id (provably uniform)
-  const int nbh = n_batch * n_heads;
-  const int bh_groups = (nbh + GPW - 1) / GPW;
-  if (wid >= 2 * S * bh_groups) return;                    // wave-uniform exit
-  const int axis = wid / (S * bh_groups);
-  const int f = (wid / bh_groups) % S;
-  const int bh = (wid % bh_groups) * GPW + lane / S;
-  const int o = lane % S;                                  // the other coordinate
-  const bool active = lane < GPW * S && bh < nbh;
-  const int bhc = active ? bh : 0;
-  const int b = bhc / n_heads, h = bhc % n_heads;
-  const int q = axis == 0 ? f * S + o : o * S + f;
-  const f16* qp = Q + ((int64_t)b * NQ + q) * ldq + h * HD;
-  float qv[HD];
-#pragma unroll
-  for (int i = 0; i < HD / 8; ++i) {
-    const f16x8 v = *(const f16x8*)(qp + 8 * i);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qv[8 * i + j] = (float)v[j];
-  }
-  const float* R = axis == 0 ? Rh : Rw;
-  if constexpr (AUG) {
-    // 32 f16 per query: cols [0,S) = rel_h, [S,2S) = rel_w, rest 0
-    f16* op = out_aug + ((int64_t)bhc * NQ + q) * 32 + axis * S;
-    float acc[S];
-#pragma unroll
-    for (int j = 0; j < S; ++j) {
-      const float* r = R + (f - j + S - 1) * HD;          // uniform
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < HD; ++i) a = fmaf(qv[i], r[i], a);
-      acc[j] = a * inv_scale;
-    }
-    if (active) {
-#pragma unroll
-      for (int j = 0; j < S; j += 2) *(f16x2*)(op + j) = (f16x2){(f16)acc[j], (f16)acc[j + 1]};
-      if (axis == 1) {
-#pragma unroll
-        for (int j = S; j < 32 - S; j += 2) *(f16x2*)(op + j) = (f16x2){(f16)0, (f16)0};
-      }
-    }
-  } else {
-    float* op = (axis == 0 ? out_h : out_w) + ((int64_t)bhc * NQ + q) * S;
-#pragma unroll 1
-    for (int j0 = 0; j0 < S; j0 += 4) {
-      f32x4 res;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const float* r = R + (f - (j0 + jj) + S - 1) * HD;  // uniform
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < HD; ++i) a = fmaf(qv[i], r[i], a);
-        res[jj] = a * inv_scale;
-      }
-      if (active) *(f32x4*)(op + j0) = res;
-    }
-  }
-}
-
-
-// MFMA form of the same terms: D[r][q] = sum_d Tab[r][d] * Q[q][d] for the stacked tables
+// MFMA form: D[r][q] = sum_d Tab[r][d] * Q[q][d] for the stacked tables
 // Tab = [rel_pos_h (2S-1 rows, padded to RT*32) ; rel_pos_w (same)], then a scattered store
 // out[q][j] = D[q_x - j + S - 1][q].  One workgroup per (batch*head, block of QB*32 queries); the table is
 // converted to f16 once into LDS (A operand via ds_read_b128), Q^T fragments come straight from HBM.

@@ -53,6 +53,40 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const f16* __restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Pillow's antialiased bilinear resize of 8-bit images, bit for bit (third-party algorithm: Pillow 12.2,
+// src/libImaging/Resample.c ImagingResampleHorizontal_8bpc / ImagingResampleVertical_8bpc): every output sample is
+//   clip8((2^21 + sum_x in[xmin + x] * k[x]) >> 22)
+// with the 22-bit fixed-point coefficients and [xmin, xmin + n) bounds computed on the host exactly as
+// precompute_coeffs / normalize_coeffs_8bpc do (inklayer_amd/resize.py).  The horizontal pass runs first and its
+// result is rounded to u8 before the vertical pass - that intermediate rounding is part of the result.
+// Reference call sites: torchvision F.resize on a PIL image in GD/datasets/transforms.py:87-117 (detector, 800
+// shorter side) and SA/utils/transforms.py:26-31 (SAM, 1024 longest side).  axis 0: along x, axis 1: along y.
+__global__ __launch_bounds__(256) void resize_pass_kernel(const uint8_t* __restrict__ in, int in_h, int in_w,
+                                                           uint8_t* __restrict__ out, int out_h, int out_w,
+                                                           const int32_t* __restrict__ bounds,
+                                                           const int32_t* __restrict__ coef, int ksize, int axis) {
+  const int64_t total = (int64_t)out_h * out_w;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int oy = (int)(i / out_w), ox = (int)(i % out_w);
+    const int o = axis == 0 ? ox : oy;
+    const int lo = bounds[2 * o], n = bounds[2 * o + 1];
+    const int32_t* k = coef + (int64_t)o * ksize;
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int x = 0; x < n; ++x) {
+      const uint8_t* px = axis == 0 ? in + ((int64_t)oy * in_w + lo + x) * 3 : in + ((int64_t)(lo + x) * in_w + ox) * 3;
+      const int kk = k[x];
+      s0 += px[0] * kk;
+      s1 += px[1] * kk;
+      s2 += px[2] * kk;
+    }
+    uint8_t* q = out + i * 3;
+    q[0] = (uint8_t)min(max(s0 >> 22, 0), 255);
+    q[1] = (uint8_t)min(max(s1 >> 22, 0), 255);
+    q[2] = (uint8_t)min(max(s2 >> 22, 0), 255);
+  }
+}
 }  // namespace
 
 extern "C" int ink_sam_patchify(const void* image_u8, int32_t h, int32_t w, int32_t L, int32_t P,
@@ -76,5 +110,31 @@ extern "C" int ink_im2col3x3_f16(const void* in_f16, int32_t B, int32_t H, int32
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                      (const f16*)in_f16, B, H, W, C, (f16*)out_f16);
+  return ink_launch_status();
+}
+
+extern "C" int ink_resize_bilinear_u8(const void* src_u8, int32_t h, int32_t w, void* dst_u8, int32_t oh, int32_t ow,
+                                      const int32_t* xbounds, const int32_t* xcoef, int32_t kx,
+                                      const int32_t* ybounds, const int32_t* ycoef, int32_t ky, void* tmp_u8,
+                                      void* stream) {
+  INK_CHECK_ARG(src_u8 && dst_u8 && h > 0 && w > 0 && oh > 0 && ow > 0);
+  const bool need_h = ow != w, need_v = oh != h;
+  INK_CHECK_ARG(need_h || need_v);
+  INK_CHECK_ARG(!need_h || (xbounds && xcoef && kx > 0));
+  INK_CHECK_ARG(!need_v || (ybounds && ycoef && ky > 0));
+  INK_CHECK_ARG(!(need_h && need_v) || tmp_u8);
+  hipStream_t s = (hipStream_t)stream;
+  auto grid = [](int64_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); };
+  const uint8_t* cur = (const uint8_t*)src_u8;
+  if (need_h) {                       // [h, w] -> [h, ow]
+    uint8_t* o = need_v ? (uint8_t*)tmp_u8 : (uint8_t*)dst_u8;
+    hipLaunchKernelGGL(resize_pass_kernel, dim3(grid((int64_t)h * ow)), dim3(256), 0, s, cur, h, w, o, h, ow, xbounds,
+                       xcoef, kx, 0);
+    cur = o;
+  }
+  if (need_v) {                       // [h, ow] -> [oh, ow]
+    hipLaunchKernelGGL(resize_pass_kernel, dim3(grid((int64_t)oh * ow)), dim3(256), 0, s, cur, h, ow,
+                       (uint8_t*)dst_u8, oh, ow, ybounds, ycoef, ky, 1);
+  }
   return ink_launch_status();
 }

@@ -235,6 +235,25 @@ def relpos_bias(q: torch.Tensor, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tenso
     return aug
 
 
+def resize_bilinear_u8(image_u8: torch.Tensor, oh: int, ow: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PIL `Image.resize((ow, oh), BILINEAR)` of an HWC uint8 RGB CUDA tensor, bit for bit (antialiased)."""
+    from .resize import plan_for
+    assert image_u8.dtype == torch.uint8 and image_u8.is_cuda and image_u8.is_contiguous()
+    h, w, c = image_u8.shape
+    assert c == 3
+    if (oh, ow) == (h, w):
+        return image_u8
+    pl = plan_for(h, w, oh, ow, image_u8.device)
+    if out is None:
+        out = torch.empty((oh, ow, 3), device=image_u8.device, dtype=torch.uint8)
+    assert out.dtype == torch.uint8 and out.is_contiguous() and tuple(out.shape) == (oh, ow, 3)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    check(_lib.lib().ink_resize_bilinear_u8(image_u8.data_ptr(), h, w, out.data_ptr(), oh, ow, ptr(pl.xb), ptr(pl.xk),
+                                            pl.kx, ptr(pl.yb), ptr(pl.yk), pl.ky, ptr(pl.tmp), _stream()),
+          "ink_resize_bilinear_u8")
+    return out
+
+
 def sam_patchify(image_u8: torch.Tensor, L: int, P: int, mean: Sequence[float],
                  std: Sequence[float], chan_reverse: bool, out: torch.Tensor) -> torch.Tensor:
     """uint8 HWC (h,w <= L) -> normalised, zero-padded f16 im2col [ (L/P)^2, 3*P*P ]."""

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import gdino as gd
+from . import ops
 from . import sam as sm
 from .ops import sam_postprocess as ops_sam_postprocess
 
@@ -40,6 +41,16 @@ def boxes_to_pixels(norm_xyxy: np.ndarray, W: int, H: int) -> torch.Tensor:
     return b
 
 
+def gpu_preprocess(img_u8: torch.Tensor, L: int):
+    """The reference's two PIL resizes of one decoded RGB sketch (HWC uint8, on the GPU), bit for bit:
+    detector input (GD/util/inference.py:39-50: shorter side 800, longer <= 1333) and SAM input
+    (SA/utils/transforms.py:26-31: longest side L).  Returns (det_u8, sam_u8), both RGB order."""
+    h, w = int(img_u8.shape[0]), int(img_u8.shape[1])
+    dh, dw = gd.resize_shape(w, h)
+    sh, sw = sm.preprocess_shape(h, w, L)
+    return ops.resize_bilinear_u8(img_u8, dh, dw), ops.resize_bilinear_u8(img_u8, sh, sw)
+
+
 class _NullCtx:
     def __enter__(self):
         return self
@@ -59,17 +70,31 @@ class InkLayerPipeline:
         self.s_det = torch.cuda.Stream(device=self.dev) if overlap else None
         self.s_seg = torch.cuda.Stream(device=self.dev) if overlap else None
 
-    def prepare(self, images_rgb: Sequence[np.ndarray]):
-        """Host side: the two PIL resizes of the reference (800 shorter side for the detector,
-        1024 longest side for SAM incl. its channel quirk), then ONE upload each."""
+    def upload(self, images_rgb: Sequence[np.ndarray]) -> List[torch.Tensor]:
+        """Decoded RGB sketches (HWC uint8, host) -> device, one transfer each.  Everything after this point -
+        both resizes, normalisation, patchify - runs on the GPU."""
+        return [torch.from_numpy(np.ascontiguousarray(im)).to(self.dev, non_blocking=True) for im in images_rgb]
+
+    def preprocess(self, raw: Sequence[torch.Tensor]):
+        """GPU side of load_image / ResizeLongestSide (Pillow-exact bilinear, `ink_resize_bilinear_u8`), plus
+        SAM's channel quirk (InkLayer/segmentor/sam.py:24-26 feeds the encoder channel-reversed pixels)."""
         det_in, sam_in, sizes = [], [], []
         L = self.seg.cfg.img_size
-        for im in images_rgb:
-            det_in.append(torch.from_numpy(np.array(gd.resize_for_detector(im))).to(self.dev, non_blocking=True))
-            rs = sm.resize_longest_side(np.ascontiguousarray(im[..., ::-1]), L)   # sam.py:24-26 channel reversal
-            sam_in.append(torch.from_numpy(np.array(rs)).to(self.dev, non_blocking=True))
-            sizes.append(((im.shape[0], im.shape[1]), tuple(rs.shape[:2])))
+        for im in raw:
+            d, s_ = gpu_preprocess(im, L)
+            det_in.append(d)
+            sam_in.append(s_.flip(-1).contiguous())
+            sizes.append(((int(im.shape[0]), int(im.shape[1])), (int(s_.shape[0]), int(s_.shape[1]))))
         return det_in, sam_in, sizes
+
+    def prepare(self, images_rgb: Sequence[np.ndarray]):
+        """upload + preprocess: (detector inputs, SAM inputs, ((H, W), (h_sam, w_sam)) per image)."""
+        return self.preprocess(self.upload(images_rgb))
+
+    @torch.no_grad()
+    def run_uploaded(self, raw: Sequence[torch.Tensor], top_n: Optional[int] = None) -> List[SketchResult]:
+        """The whole hot path D1 -> S9 from device-resident decoded sketches."""
+        return self.run_prepared(*self.preprocess(raw), top_n=top_n)
 
     @torch.no_grad()
     def run_prepared(self, det_in, sam_in, sizes, top_n: Optional[int] = None,
