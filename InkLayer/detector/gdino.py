@@ -44,7 +44,9 @@ def run_ft_dino_on_sketch(sketch_path):
     from inklayer_amd import gdino
     eng = get_model()
     image_source = np.asarray(Image.open(sketch_path).convert("RGB"))
-    resized = gdino.resize_for_detector(image_source)
-    boxes, scores = eng.detect([torch.from_numpy(resized).to(eng.dev)])[0]
+    from inklayer_amd import ops
+    raw = torch.from_numpy(np.ascontiguousarray(image_source)).to(eng.dev)
+    oh, ow = gdino.resize_shape(image_source.shape[1], image_source.shape[0])   # load_image's RandomResize([800], 1333)
+    boxes, scores = eng.detect([ops.resize_bilinear_u8(raw, oh, ow)])[0]
     normalized = cxcywh_to_xyxy(boxes.tolist()).tolist()        # cxcywh -> xyxy in float64
     return {"bboxes": normalized, "scores": scores.tolist(), "labels": ["object"] * len(normalized)}

@@ -74,8 +74,8 @@ def resize_shape(w: int, h: int, size: int = 800, max_size: int = 1333) -> Tuple
 
 
 def resize_for_detector(image_rgb: np.ndarray) -> np.ndarray:
-    """RandomResize([800], max_size=1333) of load_image (GD/util/inference.py:40-49): PIL bilinear on the
-    host (must match PIL's filter; the /255 + mean/std normalisation happens in the patchify kernel)."""
+    """RandomResize([800], max_size=1333) of load_image (GD/util/inference.py:40-49) with PIL on the host.  Not on
+    the product path any more (ops.resize_bilinear_u8 is bit-identical on the GPU); kept as the test reference."""
     from PIL import Image
     im = Image.fromarray(image_rgb)
     oh, ow = resize_shape(im.size[0], im.size[1])

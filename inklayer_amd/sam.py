@@ -63,8 +63,8 @@ def preprocess_shape(h: int, w: int, L: int) -> Tuple[int, int]:
 
 
 def resize_longest_side(img: np.ndarray, L: int) -> np.ndarray:
-    """ResizeLongestSide.apply_image (SA/utils/transforms.py:26-31): PIL bilinear on the host
-    (kept on the CPU on purpose: it must match PIL's filter bit-for-bit)."""
+    """ResizeLongestSide.apply_image (SA/utils/transforms.py:26-31) with PIL on the host.  Not on the product
+    path any more (ops.resize_bilinear_u8 is bit-identical on the GPU); kept as the reference the tests compare to."""
     from PIL import Image
     nh, nw = preprocess_shape(img.shape[0], img.shape[1], L)
     if (nh, nw) == img.shape[:2]:
@@ -412,10 +412,12 @@ class SamPredictor:
         assert image_format in ("RGB", "BGR")
         if image_format != "RGB":
             image = image[..., ::-1]
-        rs = resize_longest_side(np.ascontiguousarray(image), self.cfg.img_size)
+        # ResizeLongestSide.apply_image on the GPU (Pillow-exact, ops.resize_bilinear_u8)
+        raw = torch.from_numpy(np.ascontiguousarray(image)).to(self.engine.dev)
+        nh, nw = preprocess_shape(image.shape[0], image.shape[1], self.cfg.img_size)
+        dev_img = ops.resize_bilinear_u8(raw, nh, nw)
         self.original_size = tuple(image.shape[:2])
-        self.input_size = tuple(rs.shape[:2])
-        dev_img = torch.from_numpy(np.ascontiguousarray(rs)).to(self.engine.dev)
+        self.input_size = (nh, nw)
         self.features = self.engine.encode([dev_img])[0]
         self.is_image_set = True
 
