@@ -56,7 +56,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
   constexpr int KIT = (64 * CH + NT - 1) / NT;
   constexpr float NEG = -1e30f;
   constexpr int TILEB = 64 * KROW + 64 * VROW;   // LDS bytes of one 64-key K/V tile
-  constexpr int MAXT = ALLKV ? 4 : 1;             // ALLKV: every tile (n_k <= 256) resident at once
+  constexpr int MAXT = ALLKV ? 4 : 2;             // ALLKV: every tile (n_k <= 256) resident at once; else a double buffer
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = smem + 64 * KROW;
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
       if (tid + it * NT < 64 * CH) {
-        *(f16x8*)(sK + loff_k[it]) = kreg[it];
-        *(f16x8*)(sV + loff_v[it]) = vreg[it];
+        *(f16x8*)(sK + (t & 1) * TILEB + loff_k[it]) = kreg[it];
+        *(f16x8*)(sV + (t & 1) * TILEB + loff_v[it]) = vreg[it];
       }
     }
     if constexpr (MODE == 2 && !ALLKV) {  // one-hot (kh, kw) columns of K'
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
           const int col = c4 * 8 + j;
           e[j] = (key < p.n_k && (col == kh || col == kw)) ? (f16)1 : (f16)0;
         }
-        *(f16x8*)(sK + row * KROW + (CH + c4) * 16) = e;
+        *(f16x8*)(sK + (t & 1) * TILEB + row * KROW + (CH + c4) * 16) = e;
       }
     }
   };
@@ -301,30 +301,40 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
       load_kv_all(blk + 1);
     }
   } else {
+    // streamed K/V (everything but the windows): tiles alternate between two LDS buffers, so ONE barrier per tile
+    // is enough - it publishes tile t+1 and retires the reads of tile t - and the LDS store of tile t+1 and the
+    // global loads of tile t+2 overlap the MFMAs of tile t
     load_tile(0);
+    store_tile(0);
+    if (ntiles > 1) load_tile(1);
+    __syncthreads();
   }
   // (a wave whose 32 queries are all window padding - bottom-row windows - has nothing to compute)
   const int nt_wave = (ALLKV && !__any(q_ok)) ? 0 : ntiles;
   for (int t = 0; t < nt_wave; ++t) {
-    if constexpr (!ALLKV) {
-      __syncthreads();  // previous tile fully consumed
-      store_tile(t);
-      __syncthreads();
-      if (t + 1 < ntiles) load_tile(t + 1);  // in flight during the MFMAs below
-    }
-    const char* tK = sK + (ALLKV ? t * TILEB : 0);
-    const char* tV = sV + (ALLKV ? t * TILEB : 0);
+    const char* tK = sK + (ALLKV ? t : (t & 1)) * TILEB;
+    const char* tV = sV + (ALLKV ? t : (t & 1)) * TILEB;
     const float rh = rh_next;               // rel_h[q, kh = t]: a per-tile constant of this lane
     if constexpr (MODE == 1) {
       if (t + 1 < ntiles) rh_next = RH[t + 1];   // prefetch: never a dependent load at the top of a tile
     }
 
     f32x16 s0, s1;
+    // K fragments of the whole tile up front where the registers allow it (everything but the persistent window
+    // kernel): the S-phase MFMA chain then never waits on an LDS read issued just before it
+    constexpr bool KPRE = !ALLKV;
+    f16x8 kfa[KPRE ? NQK : 1], kfb[KPRE ? NQK : 1];
+    if constexpr (KPRE) {
+#pragma unroll
+      for (int s = 0; s < NQK; ++s) {
+        kfa[s] = *(const f16x8*)(tK + koff0 + s * 32);
+        kfb[s] = *(const f16x8*)(tK + koff1 + s * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);     // (the scheduler would sink the reads back next to their MFMAs)
+    }
     if constexpr (MODE == 1) {
-      const f16x8 k0 = *(const f16x8*)(tK + koff0);
-      const f16x8 k1 = *(const f16x8*)(tK + koff1);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[0], rw0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[0], rw1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfa[0], qf[0], rw0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfb[0], qf[0], rw1, 0, 0, 0);
     } else if constexpr (MODE == 3) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -345,8 +355,8 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
     } else {
 #pragma unroll
       for (int s = (MODE == 1 ? 1 : 0); s < NQK; ++s) {
-        const f16x8 k0 = *(const f16x8*)(tK + koff0 + s * 32);
-        const f16x8 k1 = *(const f16x8*)(tK + koff1 + s * 32);
+        const f16x8 k0 = KPRE ? kfa[s] : *(const f16x8*)(tK + koff0 + s * 32);
+        const f16x8 k1 = KPRE ? kfb[s] : *(const f16x8*)(tK + koff1 + s * 32);
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
       }
@@ -410,6 +420,13 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
         const f16x8 vf = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], o[i], 0, 0, 0);
       }
+    }
+    if constexpr (!ALLKV) {
+      if (t + 1 < ntiles) {
+        store_tile(t + 1);                       // into the buffer tile t-1 was read from
+        if (t + 2 < ntiles) load_tile(t + 2);
+      }
+      __syncthreads();
     }
   }
 
@@ -565,7 +582,7 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
 #define INK_FA_X(HD, MODE, NW, ALL)                                                                      \
   {                                                                                                        \
     constexpr int nqk_ = HD / 16 + (MODE == 2 ? 2 : 0);                                                    \
-    constexpr int lds_ = (ALL ? 4 : 1) * (64 * (((nqk_ * 2) | 1) * 16) + 64 * (((HD + 31) / 32) * 64)) +   \
+    constexpr int lds_ = (ALL ? 4 : 2) * (64 * (((nqk_ * 2) | 1) * 16) + 64 * (((HD + 31) / 32) * 64)) +   \
                          0;                                                                            \
     static bool attr_ = ((void)hipFuncSetAttribute((const void*)flash_attn_kernel<HD, MODE, NW, ALL>,      \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_), true); \

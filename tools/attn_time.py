@@ -43,3 +43,4 @@ tg = t(lambda: ops.flash_attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], rel_h
 fl = B * H * T * T * hd * 4
 print(f"global attention: {tg:7.1f} us  ({fl / tg / 1e6:.0f} TFLOP/s;  {byts / tg / 1e6:.2f} TB/s of q,k,v,o)")
 
+
