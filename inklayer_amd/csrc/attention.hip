@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
   } else {
     // streamed K/V (everything but the windows): tiles alternate between two LDS buffers, so ONE barrier per tile
     // is enough - it publishes tile t+1 and retires the reads of tile t - and the LDS store of tile t+1 and the
-    // global loads of tile t+2 overlap the MFMAs of tile t
+    // global loads of tile t+2 follow the MFMAs of tile t (issuing them first was measured slower: 1232 vs 1188 us)
     load_tile(0);
     store_tile(0);
     if (ntiles > 1) load_tile(1);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
         store_tile(t + 1);                       // into the buffer tile t-1 was read from
         if (t + 2 < ntiles) load_tile(t + 2);
       }
-      __syncthreads();
+      __syncthreads();                           // publishes tile t+1, retires the reads of tile t
     }
   }
 

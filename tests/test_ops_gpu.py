@@ -70,6 +70,29 @@ def test_gemm_epilogue_scatter_residual_scale_f16(dev):
     assert (o16.double() - ref2).abs().max().item() < 2e-3 * ref2.abs().max().item()
 
 
+@pytest.mark.parametrize("variant", [-1, 0, 10, 45])
+@pytest.mark.parametrize("M,N,K", [(300, 36, 160), (77, 252, 128), (513, 324, 192)])
+def test_gemm_f16_out_ragged_narrow_rows(dev, variant, M, N, K):
+    """f16 output whose row stride is not a multiple of 8 elements (8-byte stores) and whose last 16-B chunk is
+    cut by N, with GELU and a late (non-linear) residual - the epilogue paths the big shapes never take."""
+    from inklayer_amd import ops, _lib
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.1).half().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    _lib.lib().ink_gemm_set_variant(variant)
+    try:
+        o1 = ops.gemm(a, w, bias, out_dtype=torch.float16)
+        o2 = ops.gemm(a, w, bias, act="gelu", residual=res, out_dtype=torch.float16)
+    finally:
+        _lib.lib().ink_gemm_set_variant(-1)
+    r1 = _ref_gemm(a, w, bias, None, None, None, None, M)
+    r2 = _ref_gemm(a, w, bias, "gelu", None, res, None, M)
+    assert (o1.double() - r1).abs().max().item() < 2e-3 * r1.abs().max().item()
+    assert (o2.double() - r2).abs().max().item() < 2e-3 * r2.abs().max().item()
+
+
 @pytest.mark.parametrize("variant", [-1, 0, 10, 40, 42, 45, 47])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16])
 def test_gemm_residual_preload_rowmap(dev, variant, out_dtype):
