@@ -594,7 +594,7 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
 #define INK_FA(HD, MODE, NW) INK_FA_X(HD, MODE, NW, false)
   if (p.head_dim == 80 && p.bias_mode == 1) {
     INK_CHECK_ARG(p.rel_h && p.rel_w && p.grid_w == 64 && p.n_k % 64 == 0);
-    INK_FA(80, 1, 4);
+    INK_FA(80, 1, 8);
   } else if (p.head_dim == 80 && p.bias_mode == 2) {
     INK_CHECK_ARG(p.rel_aug && p.grid_w > 0 && p.grid_w <= 16 && p.n_k <= p.grid_w * p.grid_w && p.n_k <= 256);
     INK_CHECK_ARG(!p.tok_rows || (p.n_q == p.n_k && p.pad_k && p.pad_v &&
