@@ -50,3 +50,9 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import pytest
     with pytest.raises(_lib.InkLayerHipError):
         _lib.lib()
+
+
+def test_graft_entry_build_checks_pass():
+    """The driver's build hook: (incremental) hipcc build, ABI version of the .so == the header's, imports."""
+    import __graft_entry__ as g
+    g.build()
