@@ -100,6 +100,13 @@ def lib() -> C.CDLL:
             raise InkLayerHipError(
                 f"{p} not found: build it with `python -m inklayer_amd.build` "
                 "(there is no CPU/eager fallback for the InkLayer hot path)")
+        # In a process that also runs PyTorch-ROCm, torch's bundled HIP runtime must be the one that is loaded: the
+        # library links against libamdhip64 by SONAME, and loading it first would bring in the system ROCm runtime,
+        # on which torch's own launches then fail ("HIP launch error" on the first kernel).  Import torch first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(str(p))
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the symbol is missing
