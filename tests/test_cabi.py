@@ -16,6 +16,7 @@ def _declared_symbols():
 def test_library_exports_every_declared_symbol():
     from inklayer_amd import build, _lib
     build.build(verbose=False)
+    import torch  # noqa: F401  torch's HIP runtime first: see inklayer_amd/_lib.py lib()
     l = ctypes.CDLL(str(_lib.lib_path()))
     syms = _declared_symbols()
     assert len(syms) >= 4
