@@ -27,7 +27,15 @@ def set_gemm_trace(lst) -> None:
     _GEMM_TRACE = lst
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """Raw handle of torch's current HIP stream.  Called once per kernel launch: the public
+    `torch.cuda.current_stream()` builds a Stream object (~8 us); the raw accessor is ~0.3 us."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
