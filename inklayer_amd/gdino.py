@@ -327,6 +327,7 @@ class GDinoEngine:
         w["dim_t"] = (10000 ** (2 * torch.div(dt, 2, rounding_mode="floor") / 128)).to(dev)
         # ---- text constants (image independent: caption is hard-coded "object.", InkLayer/detector/gdino.py:18)
         self.set_text(encoded_text, token_ids)
+        self._graphs = {}
         self._plans: Dict[Tuple[int, int, int], _Plan] = {}
 
     def set_text(self, encoded_text: Optional[torch.Tensor], token_ids: Sequence[int]) -> None:
@@ -336,6 +337,7 @@ class GDinoEngine:
                              "(inklayer_amd.text_branch) or pass precomputed features")
         T = encoded_text.shape[0]
         assert T == len(token_ids) and T <= 4, "fusion kernel is specialised for captions of <= 4 tokens"
+        self._graphs = {}                              # captured forwards hold the old text tensors
         self.T = T
         self.text0 = encoded_text.detach().to(self.dev, F32).contiguous()
         sm, pid = text_masks_and_position_ids(list(token_ids))
@@ -343,6 +345,40 @@ class GDinoEngine:
         dim_t = torch.arange(256, dtype=torch.float32)
         dim_t = 10000.0 ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / 256)
         self.pos_text = _interleaved_sincos(pid.float()[:, None] * (2 * math.pi) / dim_t).to(self.dev).contiguous()
+
+    # ------------------------------------------------------------------ HIP graphs (latency mode)
+    # At batch 1 the forward is ~600 small launches whose dependency chain is launch-latency-bound: 11.4 ms eager
+    # vs 6.4 ms as a graph replay on MI355X (tools/latency_b1.py); at batch 8 the GPU work dominates and a graph
+    # changes nothing.  So forwards of at most `graph_max_batch` equal-size images are captured once per
+    # (h, w, B) into a torch.cuda.CUDAGraph with static input/output buffers and replayed afterwards.
+    # A replay does not overlap with eager work on another stream (measured: the two-stream pipeline got slower,
+    # 16.6 -> 18.5 ms at batch 1), so InkLayerPipeline's overlapped mode passes allow_graph=False; the graph serves
+    # the sequential use of the detector (run_ft_dino_on_sketch / detect), which is how the reference runs it.
+    graph_max_batch = 1
+
+    def _forward_graphed(self, images_u8: Sequence[torch.Tensor], h: int, w_: int):
+        B = len(images_u8)
+        key = (h, w_, B)
+        g = self._graphs.get(key)
+        if g is None:
+            static_in = [torch.empty_like(im) for im in images_u8]
+            for dst, src in zip(static_in, images_u8):
+                dst.copy_(src)
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):                 # warm-up off the capture: lazy attribute calls, pools, plans
+                for _ in range(2):
+                    self._forward_eager(static_in)
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward_eager(static_in)
+            g = self._graphs[key] = (graph, static_in, out)
+        graph, static_in, out = g
+        for dst, src in zip(static_in, images_u8):
+            dst.copy_(src)
+        graph.replay()
+        return out[0].clone(), out[1].clone()            # the static outputs are overwritten by the next replay
 
     def plan(self, h: int, w: int, B: int) -> _Plan:
         key = (h, w, B)
@@ -519,7 +555,7 @@ class GDinoEngine:
         return out_logits, boxes
 
     # ------------------------------------------------------------------ whole model
-    def forward(self, images_u8: Sequence[torch.Tensor], stages: Optional[dict] = None):
+    def forward(self, images_u8: Sequence[torch.Tensor], stages: Optional[dict] = None, allow_graph: bool = True):
         """images_u8: resized HWC uint8 CUDA tensors.  -> (logits [B,nq,T], boxes [B,nq,4]) on the GPU.
         Images of different sizes are run as separate equal-size groups (the reference pads a NestedTensor
         instead; it only ever sees one image per call, GD/util/inference.py:67)."""
@@ -531,12 +567,19 @@ class GDinoEngine:
             boxes = torch.empty((B, self.cfg.num_queries, 4), device=self.dev, dtype=F32)
             for sz in dict.fromkeys(sizes):
                 idx = [i for i, s_ in enumerate(sizes) if s_ == sz]
-                lg, bx = self.forward([images_u8[i] for i in idx])
+                lg, bx = self.forward([images_u8[i] for i in idx], allow_graph=allow_graph)
                 ii = torch.tensor(idx, device=self.dev)
                 logits[ii] = lg
                 boxes[ii] = bx
             return logits, boxes
         h, w_ = sizes[0]
+        if allow_graph and stages is None and 0 < B <= self.graph_max_batch:
+            return self._forward_graphed(images_u8, h, w_)
+        return self._forward_eager(images_u8, stages)
+
+    def _forward_eager(self, images_u8: Sequence[torch.Tensor], stages: Optional[dict] = None):
+        B = len(images_u8)
+        h, w_ = tuple(images_u8[0].shape[:2])
         pl = self.plan(h, w_, B)
         feats = self.backbone(images_u8, pl)
         src = self.neck(feats, pl, B)

@@ -107,7 +107,7 @@ class InkLayerPipeline:
             self.s_det.wait_stream(cur)
             self.s_seg.wait_stream(cur)
             with torch.cuda.stream(self.s_det):
-                logits, boxes = self.det.forward(det_in)
+                logits, boxes = self.det.forward(det_in, allow_graph=False)   # graphs do not overlap across streams
                 both = torch.cat([logits, boxes], dim=-1)
                 host = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
                 host.copy_(both, non_blocking=True)

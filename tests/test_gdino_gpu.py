@@ -188,3 +188,26 @@ def test_detector_batch2_and_detect_api(dev, small_dino):
     assert len(res) == 2 and res[0][0].shape == (16, 4) and res[0][1].shape == (16,)
     res = eng.detect([a])
     assert res[0][0].shape[1] == 4 and (res[0][1] > 0.2).all()
+
+
+@torch.no_grad()
+def test_detector_graph_replay_equals_eager(dev, small_dino):
+    """Batch-1 forwards go through a captured HIP graph (latency mode): the replay must reproduce the eager
+    forward bit for bit, for new pixels in the static input buffer, and a new input size gets its own graph."""
+    sd, oc, eng, text = small_dino
+    rs = np.random.RandomState(9)
+    imgs = [torch.from_numpy(rs.randint(0, 256, size=(224, 256, 3)).astype(np.uint8)).to(dev) for _ in range(3)]
+    other = torch.from_numpy(rs.randint(0, 256, size=(256, 224, 3)).astype(np.uint8)).to(dev)
+    assert eng.graph_max_batch >= 1
+    eager = [tuple(t.clone() for t in eng._forward_eager([im])) for im in imgs + [other]]
+    eng._graphs.clear()
+    for im, (el, eb) in zip(imgs + [other] + imgs, eager + eager[:3]):      # capture, replays, second size, replays
+        gl, gb = eng.forward([im])
+        assert torch.equal(gl, el) and torch.equal(gb, eb)
+    assert len(eng._graphs) == 2
+    eng.graph_max_batch = 0                                                 # and it can be switched off
+    try:
+        gl, gb = eng.forward([imgs[0]])
+        assert torch.equal(gl, eager[0][0])
+    finally:
+        eng.graph_max_batch = 1
