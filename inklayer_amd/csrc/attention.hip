@@ -15,7 +15,11 @@
 //                   rel_h[q, kh] is one scalar per tile; both are folded into the accumulator
 //                   INIT (no per-score VALU work).
 //   2 "augmented" : 14x14 windows; the bias rides in the MFMA: Q' = [q | rel(q,.)/scale],
-//                   K' = [k | onehot(kh), onehot(kw)] (two extra 16-wide k-steps).
+//                   K' = [k | onehot(kh), onehot(kw)] (two extra 16-wide k-steps).  This instance (ALLKV) keeps
+//                   all 196 keys of a window in LDS, is persistent over (window, head) blocks with register
+//                   prefetch of the next block, and can gather/scatter token rows (tok_rows) so that SAM's
+//                   window partition / padding never materialises.
+// Streamed K/V (all other instances): 64-key tiles alternate between two LDS buffers, one barrier per tile.
 #include <stdlib.h>
 #include "common.h"
 #include "../../include/inklayer_hip.h"

@@ -1,19 +1,21 @@
-// Dense projection kernel for gfx950 (MI355X): C = epilogue(A[M,K] * W[N,K]^T).
+// Dense projection kernels for gfx950 (MI355X): C = epilogue(A[M,K] * W[N,K]^T), f16 operands, f32 accumulate.
 //
-// Structure (cdna_hip_programming.md §5, "minimum 2-phase" form of T3):
-//   - 128x128 output tile per 256-thread workgroup (4 waves as 2(M) x 2(N),
-//     each wave 64x64 = 4x4 MFMA 16x16x32 f16 tiles, f32 accumulate);
-//   - operands staged HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), two LDS
-//     stages; the DMA for K-tile t+1 is in flight while tile t feeds the MFMAs;
-//   - LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle is
-//     applied to the per-lane SOURCE address and to the ds_read address
-//     (rule 21): 16-B chunk c of row r lives at chunk c ^ swz(r);
-//   - MFMA is issued "swapped" (W fragment as the A operand) so each lane ends
-//     up with 4 CONSECUTIVE output columns of one row -> 16-B epilogue accesses;
-//   - workgroup ids are remapped so each XCD (private 4 MiB L2) works on a
-//     contiguous band of M-tiles and re-reads its A panel from L2.
-// Epilogue (fused, f32): +bias, GELU/ReLU, *col_scale, +residual, optional row
-// scatter (window-unpartition / crop / un-shift), f32 or f16 store.
+// Two kernel families share one accumulator set-up / epilogue (init_wave_tile, store_wave_tile):
+//   gemm_f16_nt_pp  ping-pong: 256x256 or 256x320 tile, 8 waves in two groups staggered by one barrier, ring of
+//                   K32 granules with counted vmcnt - the SAM ViT-H projections (see its comment);
+//   gemm_f16_nt     generic BMxBN tile, WMxWN waves of (BM/WM)x(BN/WN), two LDS stages with one drain + barrier per
+//                   K-tile - 16-wave 256x256 for the other large shapes, 128x128 (K step 64 or 32) for the rest.
+// Common to both (cdna_hip_programming.md §5):
+//   - operands staged HBM -> LDS by LDS-DMA (global_load_lds_dwordx4); the LDS image is lane-linear (DMA
+//     constraint), so the bank-conflict swizzle is applied to the per-lane SOURCE address and to the ds_read address:
+//     16-B chunk c of row r lives at chunk c ^ swz(r);
+//   - MFMA 16x16x32 f16 issued "swapped" (W fragment as the A operand) so each lane ends up with 4 CONSECUTIVE
+//     output columns of one row;
+//   - workgroup ids are remapped so each XCD (private 4 MiB L2) works on a contiguous band of tiles, GROUP_M
+//     M-tiles x all N-tiles at a time, and re-reads its A / W panels from L2;
+//   - epilogue (fused, f32): +bias, GELU/ReLU, *col_scale, +residual (preloaded into the accumulators for linear
+//     GEMMs), optional row scatter (window-unpartition / crop / un-shift), f32 or f16 store as whole row segments.
+// Variant choice: ink_gemm_query_variant; everything else in the switch of ink_gemm_f16 is a measurement build.
 #include <stdlib.h>
 #include <type_traits>
 
