@@ -182,9 +182,22 @@ __global__ __launch_bounds__(256) void biattn_image_kernel(const f16* __restrict
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane / 16;
-  for (int s = blockIdx.x * 4 + wv; s < S; s += gridDim.x * 4) {
+  const int stride = gridDim.x * 4;
+  int s = blockIdx.x * 4 + wv;
+  f16x8 q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0;
+  if (s < S) {
     const f16* qp = QV + ((int64_t)b * S + s) * LD + lane * 16;
-    const f16x8 q0 = *(const f16x8*)qp, q1 = *(const f16x8*)(qp + 8);
+    q0 = *(const f16x8*)qp;
+    q1 = *(const f16x8*)(qp + 8);
+  }
+  for (; s < S; s += stride) {
+    // the next token's query row is fetched before this token's reductions (one token in flight per wave)
+    f16x8 n0 = q0, n1 = q1;
+    if (s + stride < S) {
+      const f16* np = QV + ((int64_t)b * S + s + stride) * LD + lane * 16;
+      n0 = *(const f16x8*)np;
+      n1 = *(const f16x8*)(np + 8);
+    }
     float sc[16];
     float mx = -3.0e38f;
     for (int t = 0; t < T; ++t) {
@@ -220,6 +233,8 @@ __global__ __launch_bounds__(256) void biattn_image_kernel(const f16* __restrict
     f16* op = out_v + ((int64_t)b * S + s) * E + lane * 16;
     *(f16x8*)op = o0;
     *(f16x8*)(op + 8) = o1;
+    q0 = n0;
+    q1 = n1;
   }
 }
 
@@ -268,32 +283,63 @@ __global__ __launch_bounds__(64) void biattn_colstats_combine_kernel(const float
 }
 
 // text side, pass 2: partial[b,h,chunk,t,d] = sum_{s in chunk} exp(score[s,h,t]-max) * values_v[s,h,d]
-// (the chunk's exp() values are computed ONCE into LDS, not once per output dim)
+// One workgroup per (chunk, batch): 128 threads x 8 consecutive value dims = the whole 1024-wide value half of a
+// row as ONE coalesced 2-KiB read (16 B per lane); the chunk's exp() values of all 4 heads are computed once into
+// LDS.  (The first version read one f16 per lane per row: 0.9 TB/s.)
 template <int E>
-__global__ __launch_bounds__(256) void biattn_text_partial_kernel(const float* __restrict__ scores,
-                                                                  const float* __restrict__ stats,
-                                                                  const f16* __restrict__ QV, int S, int T,
-                                                                  int chunk, float* __restrict__ partial) {
-  constexpr int H = 4, HD = E / H, LD = 2 * E;
+__global__ __launch_bounds__(E / 8) void biattn_text_partial_kernel(const float* __restrict__ scores,
+                                                                    const float* __restrict__ stats,
+                                                                    const f16* __restrict__ QV, int S, int T,
+                                                                    int chunk, float* __restrict__ partial) {
+  constexpr int H = 4, HD = E / H, LD = 2 * E, NTH = E / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* pe = (float*)smem;                                 // [chunk][T]
+  float* pe = (float*)smem;                                 // [chunk][H][T]
   const int nchunk = gridDim.x;
-  const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int d = threadIdx.x;                                // HD == 256 == blockDim
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int d0 = threadIdx.x * 8, h = d0 / HD;              // this thread's 8 dims sit inside head h
   const int s0 = c * chunk, s1 = min(S, s0 + chunk);
-  for (int i = threadIdx.x; i < (s1 - s0) * T; i += 256) {
-    const int r = i / T, t = i % T;
-    pe[i] = expf(scores[(((int64_t)b * S + s0 + r) * H + h) * T + t] - stats[((int64_t)b * H * T + h * T + t) * 2]);
+  const int HT = H * T;
+  for (int i = threadIdx.x; i < (s1 - s0) * HT; i += NTH) {
+    const int r = i / HT, k = i % HT;                       // k = head * T + t: the layout of a scores row
+    pe[i] = expf(scores[((int64_t)b * S + s0 + r) * HT + k] - stats[((int64_t)b * HT + k) * 2]);
   }
   __syncthreads();
-  float acc[16];
-  for (int t = 0; t < T; ++t) acc[t] = 0.f;
-  for (int s = s0; s < s1; ++s) {
-    const float v = (float)QV[((int64_t)b * S + s) * LD + E + h * HD + d];
-    for (int t = 0; t < T; ++t) acc[t] = fmaf(pe[(s - s0) * T + t], v, acc[t]);
+  float acc[4][8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  const f16* vp = QV + ((int64_t)b * S + s0) * LD + E + d0;
+  const int n = s1 - s0;
+  auto accum = [&](int s, const f16x8& v) {
+    const float* pr = pe + s * HT + h * T;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < T) {
+        const float w = pr[t];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(w, (float)v[j], acc[t][j]);
+      }
+    }
+  };
+  int s = 0;
+  for (; s + 8 <= n; s += 8) {                              // eight rows in flight per thread
+    f16x8 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const f16x8*)(vp + (int64_t)(s + u) * LD);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) accum(s + u, v[u]);
   }
-  for (int t = 0; t < T; ++t)
-    partial[((((int64_t)b * H + h) * nchunk + c) * T + t) * HD + d] = acc[t];
+  for (; s < n; ++s) accum(s, *(const f16x8*)(vp + (int64_t)s * LD));
+  const int dh = d0 % HD;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < T) {
+      float* o = partial + ((((int64_t)b * H + h) * nchunk + c) * T + t) * HD + dh;
+      *(f32x4*)o = (f32x4){acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+      *(f32x4*)(o + 4) = (f32x4){acc[t][4], acc[t][5], acc[t][6], acc[t][7]};
+    }
+  }
 }
 // pass 3: out_l[b*T + t, h*HD + d] = sum_chunks partial / sumexp
 template <int E>
@@ -621,7 +667,7 @@ extern "C" int ink_biattn_fusion(const void* QV_f16, const void* KL_f16, int32_t
   hipLaunchKernelGGL(biattn_colstats_partial_kernel, dim3(ncs, B), dim3(256), 0, s, scores_ws, S, 4 * T, rows_cs,
                      partial_ws);
   hipLaunchKernelGGL(biattn_colstats_combine_kernel, dim3(B), dim3(64), 0, s, partial_ws, ncs, 4 * T, stats_ws);
-  hipLaunchKernelGGL(biattn_text_partial_kernel<1024>, dim3(nchunk, 4, B), dim3(256), chunk * T * 4, s, scores_ws,
+  hipLaunchKernelGGL(biattn_text_partial_kernel<1024>, dim3(nchunk, B), dim3(128), chunk * 4 * T * 4, s, scores_ws,
                      stats_ws, (const f16*)QV_f16, S, T, chunk, partial_ws);
   hipLaunchKernelGGL(biattn_text_reduce_kernel<1024>, dim3(T, 4, B), dim3(256), 0, s, partial_ws, stats_ws, T,
                      nchunk, (f16*)out_l_f16);
