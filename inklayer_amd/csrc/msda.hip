@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const f16* __restrict__
                                                          LevelInfo li, int B, int S, int Q,
                                                          f16* __restrict__ out) {
   constexpr int M = 8, L = 4, P = 4, C = 32;
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // XCD-contiguous work order: workgroups are dealt round-robin to the 8 XCDs, so without the remap every XCD's
+  // 4 MiB L2 would gather from the value maps of ALL images (6.8 MB each); with it XCD x works on one contiguous
+  // eighth of the (image, query) space - one image's map at batch 8 - and consecutive queries sample nearby rows
+  const int64_t gid = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   const int c8 = (int)(gid & 3);
   const int64_t qm = gid >> 2;
   if (qm >= (int64_t)B * Q * M) return;
