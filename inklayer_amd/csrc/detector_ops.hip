@@ -493,6 +493,124 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const f16* __restrict__ 
   }
 }
 
+// LDS-tiled form for head_dim 16 and n_heads % 4 == 0 (the SAM decoder: 8 heads x 16).  The kernel above reads
+// 32-byte head slices at the row stride, once per query group.  Here one workgroup serves (batch entry, 4 heads):
+// a key row's 4-head slice is exactly one 128-B line, 64-key K/V tiles are staged through LDS with 16-byte loads
+// (each byte fetched once per workgroup), wave w owns queries 2w and 2w+1, lane (kl = lane / 4, hl = lane % 4)
+// streams keys kl, kl+16, ... of head hl, and the 16 key-lanes of a head are merged with in-wave shuffles.
+__global__ __launch_bounds__(256) void attn_fewq16_kernel(const f16* __restrict__ Q, int64_t ldq,
+                                                          const f16* __restrict__ K, int64_t ldk,
+                                                          const f16* __restrict__ V, int64_t ldv, int n_q,
+                                                          int n_k, int n_heads, float scale,
+                                                          const int32_t* __restrict__ q_rows,
+                                                          const int32_t* __restrict__ kv_rows,
+                                                          f16* __restrict__ O, int64_t ldo) {
+  constexpr int HD = 16, HB = 4, TK = 64, ROWB = HB * HD * 2;      // 128 B of K (or V) per key and 4-head group
+  __shared__ __attribute__((aligned(16))) char sk[TK * ROWB], sv[TK * ROWB];
+  const int hgroups = n_heads / HB;
+  const int b = blockIdx.x / hgroups, h0 = (blockIdx.x % hgroups) * HB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kl = lane >> 2, hl = lane & 3;
+  const int64_t q0 = q_rows ? (int64_t)q_rows[b] : (int64_t)b * n_q;
+  const int64_t k0 = kv_rows ? (int64_t)kv_rows[b] : (int64_t)b * n_k;
+  const int qa = 2 * wave, qb = 2 * wave + 1;
+  float qA[HD], qB[HD];
+  {
+    const f16* pa = Q + (q0 + (qa < n_q ? qa : 0)) * ldq + (h0 + hl) * HD;
+    const f16* pb = Q + (q0 + (qb < n_q ? qb : 0)) * ldq + (h0 + hl) * HD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f16x8 va = *(const f16x8*)(pa + 8 * i), vb = *(const f16x8*)(pb + 8 * i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { qA[8 * i + j] = (float)va[j] * scale; qB[8 * i + j] = (float)vb[j] * scale; }
+    }
+  }
+  float mA = -3.0e38f, lA = 0.f, mB = -3.0e38f, lB = 0.f, aA[HD], aB[HD];
+#pragma unroll
+  for (int i = 0; i < HD; ++i) aA[i] = aB[i] = 0.f;
+  // staging: 64 rows x 8 chunks of 16 B per operand = 512 chunks each; thread t moves chunks t and t + 256
+  const int c_row = tid >> 3, c_col = tid & 7;
+  for (int t0 = 0; t0 < n_k; t0 += TK) {
+    f16x8 rk[2], rv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = c_row + 32 * u;
+      rk[u] = rv[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (t0 + row < n_k) {
+        rk[u] = *(const f16x8*)(K + (k0 + t0 + row) * ldk + h0 * HD + c_col * 8);
+        rv[u] = *(const f16x8*)(V + (k0 + t0 + row) * ldv + h0 * HD + c_col * 8);
+      }
+    }
+    __syncthreads();                                   // previous tile consumed
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      *(f16x8*)(sk + (c_row + 32 * u) * ROWB + c_col * 16) = rk[u];
+      *(f16x8*)(sv + (c_row + 32 * u) * ROWB + c_col * 16) = rv[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TK / 16; ++kk) {
+      const int key = kk * 16 + kl;
+      const char* kp = sk + key * ROWB + hl * 32;
+      const char* vp = sv + key * ROWB + hl * 32;
+      const f16x8 k0v = *(const f16x8*)kp, k1v = *(const f16x8*)(kp + 16);
+      const f16x8 v0v = *(const f16x8*)vp, v1v = *(const f16x8*)(vp + 16);
+      float dA = 0.f, dB = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        dA = fmaf(qA[j], (float)k0v[j], dA); dA = fmaf(qA[8 + j], (float)k1v[j], dA);
+        dB = fmaf(qB[j], (float)k0v[j], dB); dB = fmaf(qB[8 + j], (float)k1v[j], dB);
+      }
+      if (t0 + key >= n_k) { dA = -3.0e38f; dB = -3.0e38f; }
+      {
+        const float mn = fmaxf(mA, dA), a = expf(mA - mn), pw = (t0 + key < n_k) ? expf(dA - mn) : 0.f;
+        lA = lA * a + pw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { aA[j] = fmaf(pw, (float)v0v[j], aA[j] * a); aA[8 + j] = fmaf(pw, (float)v1v[j], aA[8 + j] * a); }
+        mA = mn;
+      }
+      {
+        const float mn = fmaxf(mB, dB), a = expf(mB - mn), pw = (t0 + key < n_k) ? expf(dB - mn) : 0.f;
+        lB = lB * a + pw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { aB[j] = fmaf(pw, (float)v0v[j], aB[j] * a); aB[8 + j] = fmaf(pw, (float)v1v[j], aB[8 + j] * a); }
+        mB = mn;
+      }
+    }
+  }
+  auto merge = [&](float& m, float& l, float (&acc)[HD]) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {               // the 16 key-lanes of this head: lane bits 2..5
+      const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
+      const float mn = fmaxf(m, mo);
+      const float a = expf(m - mn), bsc = expf(mo - mn);
+      l = l * a + lo * bsc;
+#pragma unroll
+      for (int i = 0; i < HD; ++i) acc[i] = acc[i] * a + __shfl_xor(acc[i], o, 64) * bsc;
+      m = mn;
+    }
+  };
+  merge(mA, lA, aA);
+  merge(mB, lB, aB);
+  if (kl == 0) {
+    auto put = [&](int q, float l, const float (&acc)[HD]) {
+      if (q < n_q) {
+        const float inv = 1.f / l;
+        f16* op = O + ((int64_t)b * n_q + q) * ldo + (h0 + hl) * HD;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f16x8 v;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (f16)(acc[8 * i + j] * inv);
+          *(f16x8*)(op + 8 * i) = v;
+        }
+      }
+    };
+    put(qa, lA, aA);
+    put(qb, lB, aB);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Two-stage query selection: key[s] = max_t logits[b,s,t]; indices of the K largest, in descending
 // order, ties -> lower index (torch.topk leaves tie order unspecified).  One 1024-thread workgroup
@@ -706,7 +824,11 @@ extern "C" int ink_attn_fewq(const void* Q, int64_t ldq, const void* K, int64_t 
   INK_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0);
   const dim3 grid(n_batch * n_heads), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (head_dim == 16) {
+  if (head_dim == 16 && n_heads % 4 == 0) {
+    hipLaunchKernelGGL(attn_fewq16_kernel, dim3(n_batch * (n_heads / 4)), block, 0, s, (const f16*)Q, ldq,
+                       (const f16*)K, ldk, (const f16*)V, ldv, n_q, n_k, n_heads, scale, q_batch_rows, kv_batch_rows,
+                       (f16*)O, ldo);
+  } else if (head_dim == 16) {
     hipLaunchKernelGGL(attn_fewq_kernel<16>, grid, block, 0, s, (const f16*)Q, ldq, (const f16*)K, ldk,
                        (const f16*)V, ldv, n_q, n_k, n_heads, scale, q_batch_rows, kv_batch_rows, (f16*)O, ldo);
   } else if (head_dim == 32) {

@@ -258,3 +258,26 @@ def test_window_attention_token_rows_equals_padded_layout(dev):
     a4 = aug.view(nb, H, S * S, 32); r4 = aug_ref.view(nb, H, S * S, 32)
     k4 = keep.view(nb, 1, S * S, 1).expand_as(a4)
     assert torch.equal(a4[k4], r4[k4])
+
+
+@pytest.mark.parametrize("n_heads,n_k,shared", [(8, 4096, False), (8, 4096, True), (8, 1000, False), (2, 300, False)])
+def test_attn_fewq_forms(dev, n_heads, n_k, shared):
+    """SAM decoder token->image attention (7 queries x many keys, head_dim 16): the LDS-tiled kernel (n_heads % 4
+    == 0) and the generic one (n_heads = 2), per-entry keys or keys shared through kv_batch_rows, ragged key counts."""
+    import math
+    from inklayer_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(n_k + n_heads)
+    n, nq, hd = 12, 7, 16
+    nkv = 3 if shared else n
+    q = (torch.randn(n * nq, n_heads * hd, generator=g) * 0.5).half().to(dev)
+    k = (torch.randn(nkv * n_k, n_heads * hd, generator=g) * 0.5).half().to(dev)
+    v = (torch.randn(nkv * n_k, n_heads * hd, generator=g) * 0.5).half().to(dev)
+    owner = torch.arange(n, device=dev) // 4 if shared else torch.arange(n, device=dev)
+    rows = (owner * n_k).to(torch.int32) if shared else None
+    out = ops.attn_fewq(q, k, v, n_batch=n, n_heads=n_heads, head_dim=hd, scale=1 / math.sqrt(hd), n_q=nq, n_k=n_k,
+                        kv_batch_rows=rows)
+    qf = q.double().view(n, nq, n_heads, hd).transpose(1, 2)
+    kf = k.double().view(nkv, n_k, n_heads, hd).transpose(1, 2)[owner]
+    vf = v.double().view(nkv, n_k, n_heads, hd).transpose(1, 2)[owner]
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(hd), -1) @ vf).transpose(1, 2).reshape(n * nq, n_heads * hd)
+    assert (out.double() - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-5
