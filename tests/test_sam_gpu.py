@@ -190,3 +190,22 @@ def test_pipeline_mixed_sizes_and_empty_detections(dev, small_vith):
     res = pipe.run_batch(imgs)
     assert all(r.masks.shape[0] == 0 and r.boxes_xyxy_norm.shape == (0, 4) for r in res)
     det.cfg.box_threshold = 0.2
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("input_hw,orig_hw", [((1024, 1024), (1024, 1024)), ((768, 1024), (1200, 1600)), ((1024, 683), (768, 512))])
+def test_postprocess_packed_path_matches_oracle(dev, small_vith, input_hw, orig_hw):
+    """Output widths that are multiples of 4 take the 4-pixels-per-thread kernel (one packed store per lane): same
+    arithmetic as the one-pixel kernel, checked against the oracle's two F.interpolate calls + threshold."""
+    from oracle import sam_ref
+    from inklayer_amd import ops
+    sd, oc, eng = small_vith
+    rs = np.random.RandomState(21)
+    low = torch.from_numpy(rs.standard_normal((3, 1, 256, 256)).astype(np.float32))
+    ref_logits = sam_ref.postprocess_masks(oc, low, input_hw, orig_hw)[:, 0]
+    m, lg = ops.sam_postprocess(low[:, 0].contiguous().to(dev), 1024, input_hw, orig_hw, 0.0, True)
+    assert tuple(m.shape) == (3,) + tuple(orig_hw)
+    assert (lg.cpu() - ref_logits).abs().max().item() < 1e-5 * ref_logits.abs().max().item() + 1e-6
+    assert (m.cpu().bool() != (ref_logits > 0)).float().mean().item() < 1e-5
+    m2 = ops.sam_postprocess(low[:, 0].contiguous().to(dev), 1024, input_hw, orig_hw, 0.0, False)
+    assert torch.equal(m2, m)
