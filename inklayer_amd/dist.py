@@ -59,6 +59,7 @@ def broadcast_state_dict(spec: Dict[str, Tuple[Tuple[int, ...], torch.dtype]],
         by_dtype.setdefault(dt, []).append(name)
     for dt, names in by_dtype.items():
         esz = torch.empty((), dtype=dt).element_size()
+        align = max(1, 32 // esz)                      # elements per 32 bytes
         bucket: List[str] = []
         nbytes = 0
 
@@ -67,21 +68,24 @@ def broadcast_state_dict(spec: Dict[str, Tuple[Tuple[int, ...], torch.dtype]],
             if not bucket:
                 return
             numels = [int(torch.Size(spec[n][0]).numel()) for n in bucket]
-            flat = torch.empty(sum(numels), dtype=dt, device=device)
+            # every tensor starts on a 32-byte boundary of the flat buffer: the kernels read parameters with
+            # 16-byte vector loads and must see the same alignment on every rank as torch's allocator gives rank 0
+            slots = [-(-ne // align) * align for ne in numels]
+            flat = torch.zeros(sum(slots), dtype=dt, device=device)
             if rank == src:
                 off = 0
-                for n, ne in zip(bucket, numels):
+                for n, ne, sl in zip(bucket, numels, slots):
                     flat[off:off + ne].copy_(sd[n].reshape(-1))
-                    off += ne
+                    off += sl
             dist.broadcast(flat, src=src)
             off = 0
-            for n, ne in zip(bucket, numels):
+            for n, ne, sl in zip(bucket, numels, slots):
                 out[n] = flat[off:off + ne].view(spec[n][0])
-                off += ne
+                off += sl
             bucket, nbytes = [], 0
 
         for n in names:
-            sz = int(torch.Size(spec[n][0]).numel()) * esz
+            sz = -(-int(torch.Size(spec[n][0]).numel()) // align) * align * esz
             if nbytes + sz > BUCKET_BYTES and bucket:
                 flush()
             bucket.append(n)

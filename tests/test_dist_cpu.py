@@ -31,6 +31,8 @@ def _worker(rank, world, port, q):
     got = idist.broadcast_state_dict(spec, sd, "cpu")
     idist.BUCKET_BYTES = old
     chk = {k: float(v.double().sum()) for k, v in got.items()}
+    # every received tensor starts on a 32-byte boundary of its flat bucket (b.bias follows the odd-sized a.weight)
+    assert all(v.data_ptr() % 32 == 0 for v in got.values()), {k: v.data_ptr() % 32 for k, v in got.items()}
     mx = idist.max_over_ranks(float(r + 1), "cpu")
     idist.barrier()
     q.put((r, chk, idist.shard_indices(13, r, w), mx, {k: tuple(v.shape) for k, v in got.items()}))
