@@ -63,9 +63,10 @@ class InkLayerPipeline:
     def __init__(self, detector: gd.GDinoEngine, segmentor: sm.SamEngine, overlap: bool = True):
         self.det, self.seg = detector, segmentor
         self.dev = detector.dev
-        # The detector and the SAM image encoder are independent until the mask decoder needs the boxes:
-        # they run on two HIP streams.  The encoder's big GEMMs hold 16 of a CU's 32 wave slots and 128 of its
-        # 160 KB LDS, so the detector's many small latency-bound kernels co-reside instead of queueing.
+        # The detector and the SAM image encoder are independent until the mask decoder needs the boxes: they run
+        # on two HIP streams.  The encoder's GEMM workgroups fill a CU (144 KB LDS, 8 waves x 232 VGPRs), so the two
+        # streams mostly time-slice rather than co-reside; what the second stream buys is the gaps (kernel tails,
+        # the host round trip for the boxes): ~8 ms of the detector's ~20 ms per batch of 8.
         self.overlap = overlap
         self.s_det = torch.cuda.Stream(device=self.dev) if overlap else None
         self.s_seg = torch.cuda.Stream(device=self.dev) if overlap else None
