@@ -72,6 +72,12 @@ def resize_longest_side(img: np.ndarray, L: int) -> np.ndarray:
     return np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
 
 
+def _to_dev_async(t: torch.Tensor, dev) -> torch.Tensor:
+    """Small host tensor -> device through pinned memory, non-blocking.  A pageable `.to(dev)` makes the host wait
+    until the stream has drained (here: the whole image encoder) before it can queue the decoder's launches."""
+    return t.contiguous().pin_memory().to(dev, non_blocking=True)
+
+
 class SamEngine:
     """Weights packed for the HIP kernels + preallocated activations for up to `max_batch` images."""
 
@@ -315,14 +321,15 @@ class SamEngine:
         assert n > 0 and len(img_of_box) == n
         NT = 5 + 2                                         # iou + 4 mask tokens + 2 box corners
         # --- prompt encoder (_embed_boxes): host-side affine of 4n numbers, Fourier features on GPU
-        coords = ((boxes + 0.5).reshape(-1, 2) / float(L)).contiguous().to(dev)
+        coords = _to_dev_async((boxes + 0.5).reshape(-1, 2) / float(L), dev)
         sparse = ops.sam_pe_encode(coords, w["gauss"], add=w["corner"])           # [2n, E]
         tokens = torch.empty((n, NT, E), device=dev, dtype=F32)
         tokens[:, :5] = w["out_tok"]                       # plumbing copies (no math)
         tokens[:, 5:] = sparse.view(n, 2, E)
         qpe = tokens.view(n * NT, E)
         iob = torch.as_tensor(list(img_of_box), dtype=torch.int64)
-        img_rows = (iob * T).to(torch.int32).to(dev)       # first key row of each box's image
+        img_rows = _to_dev_async((iob * T).to(torch.int32), dev)       # first key row of each box's image
+        iob_dev = _to_dev_async(iob, dev)
 
         # --- image side, shared by all boxes of an image: src = emb + no_mask_embed; key_pe = dense PE
         keys0 = ops.add_f32(emb.reshape(B * T, E).contiguous(), w["no_mask"])      # [B*T, E]
@@ -364,7 +371,7 @@ class SamEngine:
             tv16 = ops.add_cvt_f16(queries)
             if keys is None:
                 # per-box copy of the image keys (repeat_interleave of mask_decoder.py:124; a pure memory copy)
-                keys = keys0.view(B, T * E).index_select(0, iob.to(dev)).view(n * T, E)
+                keys = keys0.view(B, T * E).index_select(0, iob_dev).view(n * T, E)
                 att = self._dec_attn(d + ".i2t", k16, tk16, tv16, n, T, NT, 16, keys, q_rows=img_rows)
             else:
                 att = self._dec_attn(d + ".i2t", k16, tk16, tv16, n, T, NT, 16, keys)
