@@ -27,7 +27,7 @@ def load_model(config_path=gdino_config_path, checkpoint_path=weights_path, devi
         text = weights_init.random_text_features(cfg, device)
     else:
         ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-        sd = ckpt["model"] if "model" in ckpt else ckpt
+        sd = gdino.clean_state_dict(ckpt["model"] if "model" in ckpt else ckpt)   # GD/util/inference.py:33-34
         text = text_branch.encode_caption_from_checkpoint(sd, gdino.DEFAULT_TOKEN_IDS)
     return gdino.GDinoEngine(sd, cfg, device, encoded_text=text)
 

@@ -1,16 +1,20 @@
 """bench.py — sketches/sec end-to-end (GroundingDINO Swin-T + SAM ViT-H) at 1024x1024 on N MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N)
+    or directly - bench.py then starts its N ranks itself (fresh child processes, before anything touches the GPU).
 
-A step = one pass of the hot path over one batch of B synthetic 1024x1024 sketches per GPU
-(BASELINE.json config "Full GroundingDINO Swin-T + SAM ViT-H pipeline, batch=8, 1 MI355X"): the two
-Pillow-exact resizes on the GPU -> detector forward (B images) -> host threshold/box glue (top-16 boxes per image so the work does not depend on the
-random weights) -> SAM encoder (B images) -> prompt encoder + mask decoder + postprocess
-(16 boxes per image) -> B x 16 bool masks at 1024x1024.  The decoded uint8 sketches are resident in HBM
-when the timed region starts; masks stay on the GPU, boxes/scores cross to the host (they steer the
-control flow).  Image-parallel over ranks (weak scaling), one RCCL weight broadcast at start-up, no
-per-batch collectives.  Prints ONE JSON line on rank 0.
+A step = one pass of the hot path over one batch of B synthetic 1024x1024 sketches per GPU (BASELINE.json config
+"Full GroundingDINO Swin-T + SAM ViT-H pipeline, batch=8, 1 MI355X"), HOST MEMORY TO HOST MEMORY as SURVEY §8(d) defines
+the metric: decoded RGB u8 sketches in (pinned) host memory -> upload -> the two Pillow-exact resizes on the GPU ->
+detector forward (B images) -> host threshold/box glue (top-16 boxes per image so the work does not depend on the
+random weights) -> SAM encoder (B images) -> prompt encoder + mask decoder + postprocess (16 boxes per image) ->
+B x 16 uint8 0/1 masks of 1024x1024 downloaded into pinned host memory (1 byte per pixel, the reference's numpy bool
+format; 134 MB per step), boxes/scores on the host.  Uploads and downloads ride a copy stream and overlap with the
+neighbouring step's compute (two slots); every one of the K timed steps is complete - masks in host memory - when the
+clock stops.  `device_resident` repeats the measurement without the PCIe legs (round 1's number).
+Image-parallel over ranks (weak scaling), one RCCL weight broadcast at start-up, no per-batch collectives.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -70,10 +74,14 @@ def _cpu_share() -> int:
 
 
 def cpu_baseline(n_boxes):
-    """The CPU oracle (oracle/, a port of the reference's PyTorch modules pinned by tests/golden) timed on this
-    box's host cores on a BOUNDED sample of one sketch of the same workload: GroundingDINO in full; of SAM's
-    32 ViT-H blocks one windowed and one global block are run and the encoder time is extrapolated
-    (28 x windowed + 4 x global + patch-embed + neck); the mask decoder on 4 boxes, scaled to n_boxes."""
+    """The CPU oracle (oracle/, a port of the reference's PyTorch modules pinned by tests/golden) timed on this box's
+    host cores on a BOUNDED sample of ONE sketch of the same workload (B = 1, weights resident, SURVEY §8d protocol
+    scaled to ~25 s of CPU work): every component gets one warm-up run and is then timed `reps` times, the MEDIAN is
+    used; GroundingDINO is run in full; of SAM's 32 ViT-H blocks one windowed and one global block are run and the
+    encoder time is composed as 28 x windowed + 4 x global + patch-embed + neck; the mask decoder runs on 4 boxes and
+    is scaled to n_boxes.  The JSON says so (`extrapolated`, `measured_s`)."""
+    import statistics
+    import torch.nn.functional as F
     from oracle import gdino_ref, sam_ref
     from inklayer_amd import synthetic, weights_init, sam as psam, gdino as pgd
     ncpu = _cpu_share()
@@ -87,50 +95,89 @@ def cpu_baseline(n_boxes):
     text = weights_init.random_text_features(pgd.GDinoConfig(), "cpu")
     sm, pid = gdino_ref.text_masks_and_position_ids([101, 4874, 1012, 102])
     img = synthetic.synthetic_sketch(0)
+    t_all = time.time()
+
+    def timed(fn, reps, warm=1):
+        for _ in range(warm):
+            out = fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.time()
+            out = fn()
+            ts.append(time.time() - t0)
+        return statistics.median(ts), out
+
     T = {}
     with torch.no_grad():
-        t0 = time.time()
-        x = gdino_ref.load_image(img)
-        logits, boxes = gdino_ref.detector_forward(gsd, gcfg, x[None], text, sm, pid)
+        def detector():
+            x = gdino_ref.load_image(img)
+            return gdino_ref.detector_forward(gsd, gcfg, x[None], text, sm, pid)
+        T["detector"], (logits, boxes) = timed(detector, reps=2)
+        say(f"detector {T['detector']:.2f} s (median of 2 after 1 warm-up)")
         score = logits[0].sigmoid().max(-1)[0]
         order = torch.sort(score, descending=True, stable=True)[1][:4]
         b = boxes[0][order].double().numpy()
-        T["detector"] = time.time() - t0
-        say(f"detector {T['detector']:.1f} s")
         xyxy = np.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], -1)
         pix = torch.tensor(xyxy * 1024.0).float()
-        t0 = time.time()
         xin = sam_ref.preprocess(scfg, torch.from_numpy(img[..., ::-1].copy()).permute(2, 0, 1))[None]
-        tok = sam_ref.image_encoder(ssd, scfg, xin, upto=0)
-        T["patch_embed"] = time.time() - t0
-        t0 = time.time()
-        tok = sam_ref.vit_block(ssd, scfg, 0, tok)
-        T["win_block"] = time.time() - t0
-        t0 = time.time()
-        tok = sam_ref.vit_block(ssd, scfg, 7, tok)
-        T["glob_block"] = time.time() - t0
-        say(f"ViT-H blocks: windowed {T['win_block']:.2f} s, global {T['glob_block']:.2f} s")
-        t0 = time.time()
-        import torch.nn.functional as F
-        e = tok.permute(0, 3, 1, 2)
-        e = F.conv2d(e, ssd["image_encoder.neck.0.weight"])
-        e = sam_ref._ln2d(e, ssd["image_encoder.neck.1.weight"], ssd["image_encoder.neck.1.bias"])
-        e = F.conv2d(e, ssd["image_encoder.neck.2.weight"], padding=1)
-        emb = sam_ref._ln2d(e, ssd["image_encoder.neck.3.weight"], ssd["image_encoder.neck.3.bias"])
-        T["neck"] = time.time() - t0
-        t0 = time.time()
-        low, _ = sam_ref.mask_decoder(ssd, scfg, emb, sam_ref.dense_pe(ssd, scfg), sam_ref.embed_boxes(ssd, scfg, pix))
-        masks = sam_ref.postprocess_masks(scfg, low, (1024, 1024), (1024, 1024)) > 0
-        T["decoder4"] = time.time() - t0
+        T["patch_embed"], tok = timed(lambda: sam_ref.image_encoder(ssd, scfg, xin, upto=0), reps=3)
+        T["win_block"], tok1 = timed(lambda: sam_ref.vit_block(ssd, scfg, 0, tok), reps=3)
+        T["glob_block"], tok2 = timed(lambda: sam_ref.vit_block(ssd, scfg, 7, tok1), reps=3)
+        say(f"ViT-H blocks: windowed {T['win_block']:.2f} s, global {T['glob_block']:.2f} s (medians of 3)")
+
+        def neck():
+            e = tok2.permute(0, 3, 1, 2)
+            e = F.conv2d(e, ssd["image_encoder.neck.0.weight"])
+            e = sam_ref._ln2d(e, ssd["image_encoder.neck.1.weight"], ssd["image_encoder.neck.1.bias"])
+            e = F.conv2d(e, ssd["image_encoder.neck.2.weight"], padding=1)
+            return sam_ref._ln2d(e, ssd["image_encoder.neck.3.weight"], ssd["image_encoder.neck.3.bias"])
+        T["neck"], emb = timed(neck, reps=3)
+
+        def decoder():
+            low, _ = sam_ref.mask_decoder(ssd, scfg, emb, sam_ref.dense_pe(ssd, scfg), sam_ref.embed_boxes(ssd, scfg, pix))
+            return sam_ref.postprocess_masks(scfg, low, (1024, 1024), (1024, 1024)) > 0
+        T["decoder4"], _ = timed(decoder, reps=3)
     total = (T["detector"] + T["patch_embed"] + 28 * T["win_block"] + 4 * T["glob_block"] + T["neck"]
              + T["decoder4"] * n_boxes / 4.0)
-    work = sum(T.values())
-    say(f"measured {work:.1f} s of CPU work -> {total:.1f} s per sketch extrapolated")
-    return {"value": 1.0 / total, "unit": "sketches/s", "cores": ncpu, "kind": "port",
-            "sample": f"1 synthetic 1024x1024 sketch: GroundingDINO Swin-T in full ({T['detector']:.1f} s); SAM ViT-H "
-                      f"patch-embed + 1 windowed block ({T['win_block']:.2f} s) + 1 global block ({T['glob_block']:.2f} s) "
-                      f"+ neck, encoder extrapolated as 28 x windowed + 4 x global; mask decoder + postprocess on 4 boxes "
-                      f"scaled to {n_boxes}; fp32 torch CPU oracle, {work:.1f} s measured -> {total:.1f} s per sketch"}
+    work = time.time() - t_all
+    say(f"{work:.1f} s of CPU work -> {total:.1f} s per sketch composed")
+    return {"value": 1.0 / total, "unit": "sketches/s", "cores": ncpu, "kind": "port", "extrapolated": True,
+            "measured_s": round(work, 1), "per_sketch_s": round(total, 2),
+            "sample": f"1 synthetic 1024x1024 sketch, B=1, fp32 torch CPU oracle, weights resident, every component 1 "
+                      f"warm-up then median of 2-3 runs: GroundingDINO Swin-T in full ({T['detector']:.2f} s); SAM ViT-H "
+                      f"patch-embed ({T['patch_embed']:.2f} s) + 1 windowed block ({T['win_block']:.2f} s) + 1 global "
+                      f"block ({T['glob_block']:.2f} s) + neck ({T['neck']:.2f} s), encoder composed as 28 x windowed + "
+                      f"4 x global; mask decoder + postprocess on 4 boxes ({T['decoder4']:.2f} s) scaled to {n_boxes}"}
+
+
+ATTN_ALGO_BYTES = lambda rows, width: 4.0 * rows * width * 2      # read q, k, v + write o once, f16
+PEAK_HBM_TBS = 8.0
+
+
+def attention_summary(trace, steps):
+    """North-star figure: ViT-H attention cores against the HBM roofline (algorithmic q,k,v,o bytes / kernel time)
+    and as MFMA throughput.  trace rows: ops.set_attn_trace; only head_dim-80 launches (SAM ViT-H) are counted."""
+    out = {}
+    for name, mode in (("windowed", 2), ("global", 1)):
+        rows = [t for t in trace if t[4] == 80 and t[5] == mode]
+        if not rows:
+            continue
+        us = [t[7].elapsed_time(t[8]) * 1e3 for t in rows]
+        nb, nh, nq, nk, hd = rows[0][:5]
+        width = nh * hd
+        abytes = ATTN_ALGO_BYTES(rows[0][6], width)
+        flop = 4.0 * nb * nh * nq * nk * hd
+        avg = sum(us) / len(us)
+        out[name] = {"launches_per_step": len(rows) // max(1, steps), "avg_us": avg,
+                     "algorithmic_bytes": abytes, "GBps": abytes / avg / 1e3,
+                     "frac_hbm": abytes / (avg * 1e-6) / (PEAK_HBM_TBS * 1e12),
+                     "TFLOPs": flop / avg / 1e6, "frac_mfma": flop / (avg * 1e-6) / (PEAK_F16_TFLOPS * 1e12)}
+    if out:
+        tot_b = sum(v["algorithmic_bytes"] * v["launches_per_step"] for v in out.values())
+        tot_t = sum(v["avg_us"] * v["launches_per_step"] for v in out.values())
+        out["all_32_blocks"] = {"us_per_step": tot_t, "GBps": tot_b / tot_t / 1e3,
+                                "frac_hbm": tot_b / (tot_t * 1e-6) / (PEAK_HBM_TBS * 1e12)}
+    return out
 
 
 def main():
@@ -143,7 +190,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    from inklayer_amd import dist as idist, ops, pipeline, synthetic
+    from inklayer_amd import dist as idist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: become the launcher.  Nothing in this process has touched the GPU yet (importing
+        # torch does not); the N ranks are fresh child processes running this same script.
+        rc, out0 = idist.launch_ranks([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], args.gpus)
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        sys.exit(rc)
+
+    from inklayer_amd import ops, pipeline, synthetic
     rank, world, local = idist.init_process_group()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
@@ -153,34 +209,57 @@ def main():
     B = args.batch
     # rank r owns global images r, r+world, ... (static round-robin shard); synthetic, seeded per image
     imgs = [synthetic.synthetic_sketch(i) for i in idist.shard_indices(B * world, rank, world)]
-    raw = pipe.upload(imgs)      # decoded RGB u8 sketches resident in HBM; both resizes run inside the timed step
+    host = pipe.pinned_like(imgs)      # decoded RGB u8 sketches in pinned host memory: where the timed region starts
     torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        pipe.run_uploaded(raw, top_n=args.boxes)
+    def run_steps(n):
+        """n complete host-to-host steps, software-pipelined two deep (download of step i under step i+1)."""
+        prev, last = None, None
+        for _ in range(n):
+            t = pipe.submit_host(host, top_n=args.boxes)
+            if prev is not None:
+                last = pipe.collect_host(prev)
+            prev = t
+        if prev is not None:
+            last = pipe.collect_host(prev)
+        return last
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     idist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        # (defer_sync=True would also pipeline consecutive batches; measured slower: the GPU is already saturated)
-        res = pipe.run_uploaded(raw, top_n=args.boxes)
+    res = run_steps(args.steps)
     torch.cuda.synchronize()
     idist.barrier()
     dt = time.perf_counter() - t0
     dt = idist.max_over_ranks(dt, dev)
-    # Roofline instrumentation: the same steps once more with every GEMM launch bracketed by HIP events on its
-    # launch stream, in SERIAL stream order (detector, then SAM) so that the events time the kernel itself and not
+    assert len(res) == B and res[0][3].shape == (args.boxes, 1024, 1024) and res[0][3].dtype == np.uint8
+
+    # secondary figure: the same steps with inputs and outputs resident in HBM (no PCIe legs)
+    raw = pipe.upload(imgs)
+    torch.cuda.synchronize()
+    idist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.run_uploaded(raw, top_n=args.boxes)
+    torch.cuda.synchronize()
+    idist.barrier()
+    dt_dev = idist.max_over_ranks(time.perf_counter() - t0, dev)
+
+    # Roofline instrumentation: the same steps once more with every GEMM / attention launch bracketed by HIP events on
+    # its launch stream, in SERIAL stream order (detector, then SAM) so that the events time the kernel itself and not
     # the co-scheduling delay of the two-stream overlap (which the timed region above uses).
-    trace = []
+    trace, atrace = [], []
     roof_steps = min(2, args.steps)
     if rank == 0:
         serial = pipeline.InkLayerPipeline(det, seg, overlap=False)
         ops.set_gemm_trace(trace)
+        ops.set_attn_trace(atrace)
         for _ in range(roof_steps):
             serial.run_uploaded(raw, top_n=args.boxes)
         torch.cuda.synchronize()
         ops.set_gemm_trace(None)
-    assert len(res) == B and res[0].masks.shape == (args.boxes, 1024, 1024)
+        ops.set_attn_trace(None)
 
     if rank == 0:
         from inklayer_amd import _lib
@@ -196,7 +275,7 @@ def main():
         dom_var = max(by_var, key=lambda v: sum(t[1].elapsed_time(t[2]) for t in by_var[v]))
         dom = by_var[dom_var]
         traffic = None
-        pmc = ROOT / "profiles" / "r01_gemm_pmc.json"
+        pmc = ROOT / "profiles" / "r02_gemm_pmc.json"
         if pmc.exists():      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
             pj = json.loads(pmc.read_text())
             if pj.get("variant") == dom_var:
@@ -212,12 +291,18 @@ def main():
             "metric": "sketches/sec end-to-end (GroundingDINO+SAM) at 1024x1024",
             "value": sketches / dt, "unit": "sketches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16 (MFMA, f32 accumulate; f32 residual/norm/softmax)",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 (MFMA, f32 accumulate; f32 residual/norm/softmax; split-f16 = fp32-grade operands for "
+                     "patch-embed, neck, mask decoder)",
             "data": "synthetic",
             "config": {"workload": "full GroundingDINO Swin-T + SAM ViT-H pipeline, batch=8 per GPU, "
                                    "1024x1024 synthetic sketches, 16 boxes/sketch, random-init weights",
                        "global_batch": B * world, "boxes_per_sketch": args.boxes,
-                       "parallelism": f"image-parallel x{world}", "weight_broadcast_s": round(bcast_s, 3)},
+                       "parallelism": f"image-parallel x{world}", "weight_broadcast_s": round(bcast_s, 3),
+                       "timed_region": "host to host: pinned u8 sketches -> H2D -> pipeline -> D2H of u8 masks (1 B/pixel, "
+                                       "134 MB/step at batch 8) + boxes; copies on a copy stream, 2 slots"},
+            "device_resident": {"value": sketches / dt_dev, "unit": "sketches/s", "ms_per_step": dt_dev / args.steps * 1e3,
+                                "note": "same steps with sketches and masks left in HBM (no PCIe legs); not the metric"},
             "roofline": {"bound": "mfma", "kernel": names.get(dom_var, str(dom_var)),
                          "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_TFLOPS, "traffic": traffic,
@@ -233,6 +318,7 @@ def main():
                          "note": "HIP-event brackets per launch over %d extra steps run in serial stream order right after "
                                  "the timed region (the timed region overlaps detector and SAM encoder on two streams)" % roof_steps,
                          "end_to_end_tflops": FLOP_PER_SKETCH * sketches / dt / 1e12 / world},
+            "attention": attention_summary(atrace, roof_steps),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.boxes)

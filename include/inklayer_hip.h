@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define INK_ABI_VERSION 2
+#define INK_ABI_VERSION 3
 int ink_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -76,16 +76,27 @@ int ink_gemm_query_variant(int32_t M, int32_t N, int32_t K);
  * (GD/.../swin_transformer.py:246-265).  x is f32; out is f16 and/or f32.
  * C % 4 == 0, C <= 2048.  act: INK_ACT_NONE or INK_ACT_GELU applied after the affine
  * (LayerNorm2d + GELU of SA/modeling/mask_decoder.py:54-56).
+ * split = 1: out_f16 rows are SPLIT-f16 operands [hi | lo*64 | hi/64] of 3*C columns (ldo >= 3*C, out_f32 NULL),
+ * see ink_add_split_f16.
  * --------------------------------------------------------------------- */
 int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamma, const float* beta,
                        float eps, const int32_t* gather, int32_t rows_out, int32_t C,
-                       void* out_f16, float* out_f32, int64_t ldo, int32_t act, void* stream);
+                       void* out_f16, float* out_f32, int64_t ldo, int32_t act, int32_t split, void* stream);
 
 /* f32 -> f16 conversion with optional broadcast addend:  out[i] = f16(a[i] + b[i % n_b])
  * (b may be NULL).  n % 4 == 0, n_b % 4 == 0, n % n_b == 0.  Used for the "x + pos" operands of
  * GD/.../transformer.py:783 and SA/modeling/transformer.py:164-165,178-179 (keys + key_pe). */
 int ink_add_cvt_f16(const float* a, const float* b, int64_t n_b, void* out_f16, int64_t n,
                     void* stream);
+/* Split-f16 GEMM operand: v = a[i] + b[i % n_b] (f32, rows of C columns, contiguous) is written as three
+ * f16 K-segments  out[r, 0:C] = hi = f16(v),  out[r, C:2C] = f16((v - hi) * 64),  out[r, 2C:3C] = f16(hi / 64)
+ * (out is [n / C, 3*C]).  Multiplied by ink_gemm_f16 against weights laid out [W_hi | W_hi/64 | (W - W_hi)*64]
+ * the f32 accumulator receives hi*W_hi + lo*W_hi + hi*W_lo, i.e. an fp32-grade product (~2^-21 relative) on the
+ * f16 MFMA pipe.  Used for the layers whose f16 rounding dominates the mask error (SAM neck, prompt/mask decoder,
+ * upscaler, hyper-network: SA/modeling/image_encoder.py:88-104, mask_decoder.py:112-149, transformer.py:62-240);
+ * the reference computes these in fp32. */
+int ink_add_split_f16(const float* a, const float* b, int64_t n_b, void* out_f16, int64_t n, int32_t C,
+                      void* stream);
 /* Same with an f32 result (src = image_embeddings + dense_prompt, SA/modeling/mask_decoder.py:124-125). */
 int ink_add_f32(const float* a, const float* b, int64_t n_b, float* out, int64_t n, void* stream);
 
@@ -151,10 +162,12 @@ int ink_relpos_bias(const void* Q, int64_t ldq, const float* rel_pos_h, const fl
  * im2col matrix [ (L/P)^2, 3*P*P ] (column = c*P*P + ky*P + kx, matching proj.weight.view(D,-1)),
  * with (x - mean[c]) / std[c] applied and the bottom/right padding left at 0.
  * mean3 / std3 are HOST pointers.  chan_reverse != 0 reads channel 2-c (the BGR/RGB quirk of
- * InkLayer/segmentor/sam.py:24-26 without an extra host copy). */
+ * InkLayer/segmentor/sam.py:24-26 without an extra host copy).  split = 1: rows are split-f16 operands
+ * [hi | lo*64 | hi/64] of 3*(3*P*P) columns (see ink_add_split_f16): the patch embedding is the one ViT-H
+ * projection whose rounding error stays in the residual stream of all 32 blocks. */
 int ink_sam_patchify(const void* image_u8, int32_t h, int32_t w, int32_t L, int32_t P,
-                     const float* mean3, const float* std3, int32_t chan_reverse, void* out_f16,
-                     void* stream);
+                     const float* mean3, const float* std3, int32_t chan_reverse, int32_t split,
+                     void* out_f16, void* stream);
 
 /* Pillow's antialiased bilinear resize of an HWC uint8 RGB image, bit for bit: the `F.resize` of
  * load_image (GD/util/inference.py:39-50, GD/datasets/transforms.py:87-117: shorter side 800, max 1333) and
@@ -256,20 +269,25 @@ int ink_biattn_fusion(const void* QV_f16, const void* KL_f16, int32_t B, int32_t
                       float scale, float* scores_ws, float* stats_ws, float* partial_ws, int32_t chunk,
                       void* out_v_f16, void* out_l_f16, void* stream);
 
-/* softmax(scale q k^T [+ blocked -> -inf]) v against n_k <= 16 keys; f16 rows, head h at columns
- * [h*hd,(h+1)*hd), hd in {16,32,64}; blocked: u8 [n_q, n_k] (1 = not allowed) or NULL.
- * Text self-attention (transformer_vanilla.py:114-116) and decoder text cross-attention
- * (transformer.py:893-900). */
+/* softmax(scale q k^T [+ blocked -> -inf]) v against n_k <= 16 keys; head h at columns
+ * [h*hd,(h+1)*hd), hd in {16,32,64}; blocked: u8 [n_q, n_k] (1 = not allowed) or NULL.  io_f32 = 0: Q/K/V/O are
+ * f16 rows, 1: f32 rows (ld* in elements either way; the math is f32 in both).  q_batch_rows (int32 [B] or NULL):
+ * first Q row of batch entry b (default b*n_q); keys and the output are dense.
+ * Text self-attention (transformer_vanilla.py:114-116), decoder text cross-attention (transformer.py:893-900) and,
+ * with f32 rows, the SAM mask decoder's token self-attention and image -> token attention
+ * (SA/modeling/transformer.py:151-182: 7 x 7 and 4096 x 7). */
 int ink_attn_fewkeys(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                      int32_t B, int32_t n_q, int32_t n_k, int32_t n_heads, int32_t head_dim, float scale,
-                     const uint8_t* blocked, void* O, int64_t ldo, void* stream);
+                     const uint8_t* blocked, const int32_t* q_batch_rows, int32_t io_f32, void* O, int64_t ldo,
+                     void* stream);
 
 /* softmax(scale q k^T) v for n_q <= 8 queries per batch entry against MANY keys (SAM decoder tokens ->
- * image: 7 x 4096, SA/modeling/transformer.py:163-168): f16 rows, head h at columns [h*hd,(h+1)*hd),
- * hd in {16,32}; q_batch_rows / kv_batch_rows as in InkAttn; O dense f16 [n_batch*n_q, ..]. */
+ * image: 7 x 4096, SA/modeling/transformer.py:163-168): head h at columns [h*hd,(h+1)*hd),
+ * hd in {16,32}; q_batch_rows / kv_batch_rows as in InkAttn; O dense [n_batch*n_q, ..].  io_f32 = 0: f16 rows,
+ * 1: f32 rows (head_dim 16 with n_heads % 4 == 0 only). */
 int ink_attn_fewq(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                   int32_t n_batch, int32_t n_q, int32_t n_k, int32_t n_heads, int32_t head_dim, float scale,
-                  const int32_t* q_batch_rows, const int32_t* kv_batch_rows, void* O, int64_t ldo,
+                  const int32_t* q_batch_rows, const int32_t* kv_batch_rows, int32_t io_f32, void* O, int64_t ldo,
                   void* stream);
 
 /* Two-stage query selection (transformer.py:293-300): indices of the K largest max_t logits[b,s,t],

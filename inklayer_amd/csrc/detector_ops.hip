@@ -357,36 +357,56 @@ __global__ __launch_bounds__(256) void biattn_text_reduce_kernel(const float* __
 // Attention against a handful of keys (n_k <= 16): text self-attention (4x4, block-diagonal mask,
 // transformer_vanilla.py:114-116) and decoder text cross-attention (900 x 4, transformer.py:893-900).
 // One thread per (batch, query, head).
-template <int HD>
-__global__ __launch_bounds__(256) void attn_fewkeys_kernel(const f16* __restrict__ Q, int64_t ldq,
-                                                           const f16* __restrict__ K, int64_t ldk,
-                                                           const f16* __restrict__ V, int64_t ldv, int B,
+// 8 consecutive head-dim elements of an f16 or f32 row, as f32
+__device__ __forceinline__ void load8(const f16* p, float* d) {
+  const f16x8 v = *(const f16x8*)p;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] = (float)v[j];
+}
+__device__ __forceinline__ void load8(const float* p, float* d) {
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { d[j] = a[j]; d[4 + j] = b[j]; }
+}
+__device__ __forceinline__ void store8(f16* p, const float* d) {
+  f16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (f16)d[j];
+  *(f16x8*)p = v;
+}
+__device__ __forceinline__ void store8(float* p, const float* d) {
+  *(f32x4*)p = (f32x4){d[0], d[1], d[2], d[3]};
+  *(f32x4*)(p + 4) = (f32x4){d[4], d[5], d[6], d[7]};
+}
+
+template <int HD, typename T>
+__global__ __launch_bounds__(256) void attn_fewkeys_kernel(const T* __restrict__ Q, int64_t ldq,
+                                                           const T* __restrict__ K, int64_t ldk,
+                                                           const T* __restrict__ V, int64_t ldv, int B,
                                                            int n_q, int n_k, int n_heads, float scale,
                                                            const uint8_t* __restrict__ blocked,
-                                                           f16* __restrict__ O, int64_t ldo) {
+                                                           const int32_t* __restrict__ q_rows,
+                                                           T* __restrict__ O, int64_t ldo) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (int64_t)B * n_q * n_heads) return;
   const int h = (int)(gid % n_heads);
   const int64_t bq = gid / n_heads;
   const int b = (int)(bq / n_q), q = (int)(bq % n_q);
   float qv[HD];
-  const f16* qp = Q + bq * ldq + h * HD;
+  const T* qp = Q + (q_rows ? (int64_t)q_rows[b] + q : bq) * ldq + h * HD;
 #pragma unroll
-  for (int i = 0; i < HD / 8; ++i) {
-    const f16x8 v = *(const f16x8*)(qp + 8 * i);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qv[8 * i + j] = (float)v[j];
-  }
+  for (int i = 0; i < HD / 8; ++i) load8(qp + 8 * i, qv + 8 * i);
   float sc[16];
   float mx = -3.0e38f;
   for (int t = 0; t < n_k; ++t) {
-    const f16* kp = K + ((int64_t)b * n_k + t) * ldk + h * HD;
+    const T* kp = K + ((int64_t)b * n_k + t) * ldk + h * HD;
     float d = 0.f;
 #pragma unroll
     for (int i = 0; i < HD / 8; ++i) {
-      const f16x8 v = *(const f16x8*)(kp + 8 * i);
+      float kv[8];
+      load8(kp + 8 * i, kv);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) d = fmaf(qv[8 * i + j], (float)v[j], d);
+      for (int j = 0; j < 8; ++j) d = fmaf(qv[8 * i + j], kv[j], d);
     }
     d *= scale;
     if (blocked && blocked[q * n_k + t]) d = -3.0e38f;
@@ -400,23 +420,19 @@ __global__ __launch_bounds__(256) void attn_fewkeys_kernel(const f16* __restrict
 #pragma unroll
   for (int i = 0; i < HD; ++i) acc[i] = 0.f;
   for (int t = 0; t < n_k; ++t) {
-    const f16* vp = V + ((int64_t)b * n_k + t) * ldv + h * HD;
+    const T* vp = V + ((int64_t)b * n_k + t) * ldv + h * HD;
     const float pw = sc[t] * inv;
 #pragma unroll
     for (int i = 0; i < HD / 8; ++i) {
-      const f16x8 v = *(const f16x8*)(vp + 8 * i);
+      float vv[8];
+      load8(vp + 8 * i, vv);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[8 * i + j] = fmaf(pw, (float)v[j], acc[8 * i + j]);
+      for (int j = 0; j < 8; ++j) acc[8 * i + j] = fmaf(pw, vv[j], acc[8 * i + j]);
     }
   }
-  f16* op = O + bq * ldo + h * HD;
+  T* op = O + bq * ldo + h * HD;
 #pragma unroll
-  for (int i = 0; i < HD / 8; ++i) {
-    f16x8 v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (f16)acc[8 * i + j];
-    *(f16x8*)(op + 8 * i) = v;
-  }
+  for (int i = 0; i < HD / 8; ++i) store8(op + 8 * i, acc + 8 * i);
 }
 
 
@@ -498,15 +514,20 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const f16* __restrict__ 
 // a key row's 4-head slice is exactly one 128-B line, 64-key K/V tiles are staged through LDS with 16-byte loads
 // (each byte fetched once per workgroup), wave w owns queries 2w and 2w+1, lane (kl = lane / 4, hl = lane % 4)
 // streams keys kl, kl+16, ... of head hl, and the 16 key-lanes of a head are merged with in-wave shuffles.
-__global__ __launch_bounds__(256) void attn_fewq16_kernel(const f16* __restrict__ Q, int64_t ldq,
-                                                          const f16* __restrict__ K, int64_t ldk,
-                                                          const f16* __restrict__ V, int64_t ldv, int n_q,
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fewq16_kernel(const T* __restrict__ Q, int64_t ldq,
+                                                          const T* __restrict__ K, int64_t ldk,
+                                                          const T* __restrict__ V, int64_t ldv, int n_q,
                                                           int n_k, int n_heads, float scale,
                                                           const int32_t* __restrict__ q_rows,
                                                           const int32_t* __restrict__ kv_rows,
-                                                          f16* __restrict__ O, int64_t ldo) {
-  constexpr int HD = 16, HB = 4, TK = 64, ROWB = HB * HD * 2;      // 128 B of K (or V) per key and 4-head group
-  __shared__ __attribute__((aligned(16))) char sk[TK * ROWB], sv[TK * ROWB];
+                                                          T* __restrict__ O, int64_t ldo) {
+  constexpr int HD = 16, HB = 4, TK = 64;
+  constexpr int ROWE = HB * HD;                      // elements of K (or V) per key and 4-head group (one 128-B line in f16)
+  constexpr int CH = 16 / (int)sizeof(T);            // elements per 16-byte chunk
+  constexpr int NCH = ROWE / CH;                     // chunks per row: 8 (f16) / 16 (f32)
+  constexpr int NU = TK * NCH / 256;                 // chunks per thread and operand: 2 / 4
+  __shared__ __attribute__((aligned(16))) T sk[TK * ROWE], sv[TK * ROWE];
   const int hgroups = n_heads / HB;
   const int b = blockIdx.x / hgroups, h0 = (blockIdx.x % hgroups) * HB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -516,64 +537,67 @@ __global__ __launch_bounds__(256) void attn_fewq16_kernel(const f16* __restrict_
   const int qa = 2 * wave, qb = 2 * wave + 1;
   float qA[HD], qB[HD];
   {
-    const f16* pa = Q + (q0 + (qa < n_q ? qa : 0)) * ldq + (h0 + hl) * HD;
-    const f16* pb = Q + (q0 + (qb < n_q ? qb : 0)) * ldq + (h0 + hl) * HD;
+    const T* pa = Q + (q0 + (qa < n_q ? qa : 0)) * ldq + (h0 + hl) * HD;
+    const T* pb = Q + (q0 + (qb < n_q ? qb : 0)) * ldq + (h0 + hl) * HD;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const f16x8 va = *(const f16x8*)(pa + 8 * i), vb = *(const f16x8*)(pb + 8 * i);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { qA[8 * i + j] = (float)va[j] * scale; qB[8 * i + j] = (float)vb[j] * scale; }
+      load8(pa + 8 * i, qA + 8 * i);
+      load8(pb + 8 * i, qB + 8 * i);
     }
+#pragma unroll
+    for (int j = 0; j < HD; ++j) { qA[j] *= scale; qB[j] *= scale; }
   }
   float mA = -3.0e38f, lA = 0.f, mB = -3.0e38f, lB = 0.f, aA[HD], aB[HD];
 #pragma unroll
   for (int i = 0; i < HD; ++i) aA[i] = aB[i] = 0.f;
-  // staging: 64 rows x 8 chunks of 16 B per operand = 512 chunks each; thread t moves chunks t and t + 256
-  const int c_row = tid >> 3, c_col = tid & 7;
+  // staging: TK rows x NCH chunks of 16 B per operand; thread t moves chunks t, t + 256, ...
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   for (int t0 = 0; t0 < n_k; t0 += TK) {
-    f16x8 rk[2], rv[2];
+    u32x4 rk[NU], rv[NU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int row = c_row + 32 * u;
-      rk[u] = rv[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int u = 0; u < NU; ++u) {
+      const int c = tid + 256 * u, row = c / NCH, col = c % NCH;
+      rk[u] = rv[u] = (u32x4){0u, 0u, 0u, 0u};
       if (t0 + row < n_k) {
-        rk[u] = *(const f16x8*)(K + (k0 + t0 + row) * ldk + h0 * HD + c_col * 8);
-        rv[u] = *(const f16x8*)(V + (k0 + t0 + row) * ldv + h0 * HD + c_col * 8);
+        rk[u] = *(const u32x4*)(K + (k0 + t0 + row) * ldk + h0 * HD + col * CH);
+        rv[u] = *(const u32x4*)(V + (k0 + t0 + row) * ldv + h0 * HD + col * CH);
       }
     }
     __syncthreads();                                   // previous tile consumed
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      *(f16x8*)(sk + (c_row + 32 * u) * ROWB + c_col * 16) = rk[u];
-      *(f16x8*)(sv + (c_row + 32 * u) * ROWB + c_col * 16) = rv[u];
+    for (int u = 0; u < NU; ++u) {
+      const int c = tid + 256 * u, row = c / NCH, col = c % NCH;
+      *(u32x4*)(sk + row * ROWE + col * CH) = rk[u];
+      *(u32x4*)(sv + row * ROWE + col * CH) = rv[u];
     }
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < TK / 16; ++kk) {
       const int key = kk * 16 + kl;
-      const char* kp = sk + key * ROWB + hl * 32;
-      const char* vp = sv + key * ROWB + hl * 32;
-      const f16x8 k0v = *(const f16x8*)kp, k1v = *(const f16x8*)(kp + 16);
-      const f16x8 v0v = *(const f16x8*)vp, v1v = *(const f16x8*)(vp + 16);
+      float kf[HD], vf[HD];
+      load8(sk + key * ROWE + hl * HD, kf);
+      load8(sk + key * ROWE + hl * HD + 8, kf + 8);
+      load8(sv + key * ROWE + hl * HD, vf);
+      load8(sv + key * ROWE + hl * HD + 8, vf + 8);
       float dA = 0.f, dB = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        dA = fmaf(qA[j], (float)k0v[j], dA); dA = fmaf(qA[8 + j], (float)k1v[j], dA);
-        dB = fmaf(qB[j], (float)k0v[j], dB); dB = fmaf(qB[8 + j], (float)k1v[j], dB);
+        dA = fmaf(qA[j], kf[j], dA); dA = fmaf(qA[8 + j], kf[8 + j], dA);
+        dB = fmaf(qB[j], kf[j], dB); dB = fmaf(qB[8 + j], kf[8 + j], dB);
       }
       if (t0 + key >= n_k) { dA = -3.0e38f; dB = -3.0e38f; }
       {
         const float mn = fmaxf(mA, dA), a = expf(mA - mn), pw = (t0 + key < n_k) ? expf(dA - mn) : 0.f;
         lA = lA * a + pw;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { aA[j] = fmaf(pw, (float)v0v[j], aA[j] * a); aA[8 + j] = fmaf(pw, (float)v1v[j], aA[8 + j] * a); }
+        for (int j = 0; j < HD; ++j) aA[j] = fmaf(pw, vf[j], aA[j] * a);
         mA = mn;
       }
       {
         const float mn = fmaxf(mB, dB), a = expf(mB - mn), pw = (t0 + key < n_k) ? expf(dB - mn) : 0.f;
         lB = lB * a + pw;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { aB[j] = fmaf(pw, (float)v0v[j], aB[j] * a); aB[8 + j] = fmaf(pw, (float)v1v[j], aB[8 + j] * a); }
+        for (int j = 0; j < HD; ++j) aB[j] = fmaf(pw, vf[j], aB[j] * a);
         mB = mn;
       }
     }
@@ -593,17 +617,14 @@ __global__ __launch_bounds__(256) void attn_fewq16_kernel(const f16* __restrict_
   merge(mA, lA, aA);
   merge(mB, lB, aB);
   if (kl == 0) {
-    auto put = [&](int q, float l, const float (&acc)[HD]) {
+    auto put = [&](int q, float l, float (&acc)[HD]) {
       if (q < n_q) {
         const float inv = 1.f / l;
-        f16* op = O + ((int64_t)b * n_q + q) * ldo + (h0 + hl) * HD;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          f16x8 v;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (f16)(acc[8 * i + j] * inv);
-          *(f16x8*)(op + 8 * i) = v;
-        }
+        for (int i = 0; i < HD; ++i) acc[i] *= inv;
+        T* op = O + ((int64_t)b * n_q + q) * ldo + (h0 + hl) * HD;
+        store8(op, acc);
+        store8(op + 8, acc + 8);
       }
     };
     put(qa, lA, aA);
@@ -794,38 +815,43 @@ extern "C" int ink_biattn_fusion(const void* QV_f16, const void* KL_f16, int32_t
 
 extern "C" int ink_attn_fewkeys(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V,
                                 int64_t ldv, int32_t B, int32_t n_q, int32_t n_k, int32_t n_heads,
-                                int32_t head_dim, float scale, const uint8_t* blocked, void* O, int64_t ldo,
+                                int32_t head_dim, float scale, const uint8_t* blocked,
+                                const int32_t* q_batch_rows, int32_t io_f32, void* O, int64_t ldo,
                                 void* stream) {
   INK_CHECK_ARG(Q && K && V && O && B > 0 && n_q > 0 && n_k > 0 && n_k <= 16 && n_heads > 0);
   INK_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0);
+  INK_CHECK_ARG(io_f32 == 0 || io_f32 == 1);
   const int64_t total = (int64_t)B * n_q * n_heads;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (head_dim == 32) {
-    hipLaunchKernelGGL(attn_fewkeys_kernel<32>, grid, block, 0, s, (const f16*)Q, ldq, (const f16*)K, ldk,
-                       (const f16*)V, ldv, B, n_q, n_k, n_heads, scale, blocked, (f16*)O, ldo);
-  } else if (head_dim == 64) {
-    hipLaunchKernelGGL(attn_fewkeys_kernel<64>, grid, block, 0, s, (const f16*)Q, ldq, (const f16*)K, ldk,
-                       (const f16*)V, ldv, B, n_q, n_k, n_heads, scale, blocked, (f16*)O, ldo);
-  } else if (head_dim == 16) {
-    hipLaunchKernelGGL(attn_fewkeys_kernel<16>, grid, block, 0, s, (const f16*)Q, ldq, (const f16*)K, ldk,
-                       (const f16*)V, ldv, B, n_q, n_k, n_heads, scale, blocked, (f16*)O, ldo);
-  } else {
-    return INK_ERR_ARG;
-  }
+#define INK_FEWKEYS(HD, T)                                                                                     \
+  hipLaunchKernelGGL((attn_fewkeys_kernel<HD, T>), grid, block, 0, s, (const T*)Q, ldq, (const T*)K, ldk,      \
+                     (const T*)V, ldv, B, n_q, n_k, n_heads, scale, blocked, q_batch_rows, (T*)O, ldo)
+  if (head_dim == 32 && !io_f32) INK_FEWKEYS(32, f16);
+  else if (head_dim == 64 && !io_f32) INK_FEWKEYS(64, f16);
+  else if (head_dim == 16 && !io_f32) INK_FEWKEYS(16, f16);
+  else if (head_dim == 32) INK_FEWKEYS(32, float);
+  else if (head_dim == 16) INK_FEWKEYS(16, float);
+  else return INK_ERR_ARG;
+#undef INK_FEWKEYS
   return ink_launch_status();
 }
 
 extern "C" int ink_attn_fewq(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                              int32_t n_batch, int32_t n_q, int32_t n_k, int32_t n_heads, int32_t head_dim,
-                             float scale, const int32_t* q_batch_rows, const int32_t* kv_batch_rows, void* O,
-                             int64_t ldo, void* stream) {
+                             float scale, const int32_t* q_batch_rows, const int32_t* kv_batch_rows,
+                             int32_t io_f32, void* O, int64_t ldo, void* stream) {
   INK_CHECK_ARG(Q && K && V && O && n_batch > 0 && n_q > 0 && n_q <= 8 && n_k > 0 && n_heads > 0);
   INK_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0);
+  INK_CHECK_ARG(io_f32 == 0 || (io_f32 == 1 && head_dim == 16 && n_heads % 4 == 0));
   const dim3 grid(n_batch * n_heads), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (head_dim == 16 && n_heads % 4 == 0) {
-    hipLaunchKernelGGL(attn_fewq16_kernel, dim3(n_batch * (n_heads / 4)), block, 0, s, (const f16*)Q, ldq,
+  if (head_dim == 16 && n_heads % 4 == 0 && io_f32) {
+    hipLaunchKernelGGL(attn_fewq16_kernel<float>, dim3(n_batch * (n_heads / 4)), block, 0, s, (const float*)Q, ldq,
+                       (const float*)K, ldk, (const float*)V, ldv, n_q, n_k, n_heads, scale, q_batch_rows,
+                       kv_batch_rows, (float*)O, ldo);
+  } else if (head_dim == 16 && n_heads % 4 == 0) {
+    hipLaunchKernelGGL(attn_fewq16_kernel<f16>, dim3(n_batch * (n_heads / 4)), block, 0, s, (const f16*)Q, ldq,
                        (const f16*)K, ldk, (const f16*)V, ldv, n_q, n_k, n_heads, scale, q_batch_rows, kv_batch_rows,
                        (f16*)O, ldo);
   } else if (head_dim == 16) {

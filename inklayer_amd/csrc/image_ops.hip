@@ -11,7 +11,7 @@ namespace {
 __global__ __launch_bounds__(256) void sam_patchify_kernel(const uint8_t* __restrict__ img, int h,
                                                            int w, int L, int P, f32x4 mean_is,
                                                            f32x4 istd, f16* __restrict__ out,
-                                                           int chan_reverse) {
+                                                           int chan_reverse, int split) {
   const int g = L / P;
   const int KP = 3 * P * P;
   const int chunks_per_tok = KP / 8;
@@ -22,15 +22,24 @@ __global__ __launch_bounds__(256) void sam_patchify_kernel(const uint8_t* __rest
     const int c = col / (P * P), ky = (col / P) % P, kx0 = col % P;
     const int y = (tok / g) * P + ky, x0 = (tok % g) * P + kx0;
     const int cs = chan_reverse ? 2 - c : c;
-    f16x8 v;
+    f16x8 v, lo, hs;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int x = x0 + j;
       float f = 0.f;  // padded area is zero AFTER normalisation (SA/modeling/sam.py:167-173)
       if (y < h && x < w) f = ((float)img[((int64_t)y * w + x) * 3 + cs] - mean_is[c]) * istd[c];
       v[j] = (f16)f;
+      lo[j] = (f16)((f - (float)v[j]) * 64.0f);      // split-f16 operand segments, see ink_add_split_f16
+      hs[j] = (f16)((float)v[j] * 0.015625f);
     }
-    *(f16x8*)(out + (int64_t)tok * KP + col) = v;
+    if (split) {
+      f16* o = out + (int64_t)tok * 3 * KP + col;
+      *(f16x8*)o = v;
+      *(f16x8*)(o + KP) = lo;
+      *(f16x8*)(o + 2 * KP) = hs;
+    } else {
+      *(f16x8*)(out + (int64_t)tok * KP + col) = v;
+    }
   }
 }
 
@@ -91,15 +100,15 @@ __global__ __launch_bounds__(256) void resize_pass_kernel(const uint8_t* __restr
 
 extern "C" int ink_sam_patchify(const void* image_u8, int32_t h, int32_t w, int32_t L, int32_t P,
                                 const float* mean3, const float* std3, int32_t chan_reverse,
-                                void* out_f16, void* stream) {
-  INK_CHECK_ARG(image_u8 && out_f16 && mean3 && std3);
+                                int32_t split, void* out_f16, void* stream) {
+  INK_CHECK_ARG(image_u8 && out_f16 && mean3 && std3 && (split == 0 || split == 1));
   INK_CHECK_ARG(h > 0 && w > 0 && h <= L && w <= L && P % 8 == 0 && L % P == 0);
   const f32x4 m = {mean3[0], mean3[1], mean3[2], 0.f};
   const f32x4 is = {1.f / std3[0], 1.f / std3[1], 1.f / std3[2], 0.f};
   const int64_t total = (int64_t)(L / P) * (L / P) * (3 * P * P / 8);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(sam_patchify_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                     (const uint8_t*)image_u8, h, w, L, P, m, is, (f16*)out_f16, chan_reverse);
+                     (const uint8_t*)image_u8, h, w, L, P, m, is, (f16*)out_f16, chan_reverse, split);
   return ink_launch_status();
 }
 

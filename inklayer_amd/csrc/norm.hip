@@ -4,12 +4,30 @@
 
 namespace {
 
+// Split-f16 operands: an f32 value v travels into an f16 MFMA GEMM as THREE K-segments
+//   [ hi | (v - hi) * 64 | hi / 64 ],  hi = f16(v),
+// against weights laid out as [ W_hi | W_hi / 64 | (W - W_hi) * 64 ], so the accumulator receives
+// hi*W_hi + lo*W_hi + hi*W_lo = v*W to ~2^-21 relative.  The powers of two keep both low parts inside f16's
+// NORMAL range for |v|, |W| >= 4e-3 (no reliance on how the MFMA unit treats f16 subnormals).
+__device__ __forceinline__ void split_store(f16* o, int C, const f32x4& y) {
+  f16x4 hi, lo, hs;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (f16)y[e];
+    lo[e] = (f16)((y[e] - (float)hi[e]) * 64.0f);
+    hs[e] = (f16)((float)hi[e] * 0.015625f);
+  }
+  *(f16x4*)o = hi;
+  *(f16x4*)(o + C) = lo;
+  *(f16x4*)(o + 2 * C) = hs;
+}
+
 // one wave per output row; row kept in registers (C <= 2048 -> <= 8 float4 per lane)
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, const int32_t* __restrict__ gather, int rows_out,
-    int C, f16* __restrict__ out_h, float* __restrict__ out_f, int64_t ldo, int act) {
+    int C, f16* __restrict__ out_h, float* __restrict__ out_f, int64_t ldo, int act, int split) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows_out) return;
@@ -17,7 +35,8 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
   const int src = gather ? gather[row] : row;
   if (src < 0) {  // padded token: zeros (the reference pads AFTER the norm)
     for (int v = lane; v < nv; v += 64) {
-      if (out_h) *(f16x4*)(out_h + row * ldo + v * 4) = (f16x4){0, 0, 0, 0};
+      if (out_h && split) split_store(out_h + row * ldo + v * 4, C, (f32x4){0.f, 0.f, 0.f, 0.f});
+      else if (out_h) *(f16x4*)(out_h + row * ldo + v * 4) = (f16x4){0, 0, 0, 0};
       if (out_f) *(f32x4*)(out_f + row * ldo + v * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     return;
@@ -53,9 +72,25 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = gelu_erf(y[e]);
       }
-      if (out_h) *(f16x4*)(out_h + row * ldo + v * 4) = (f16x4){(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+      if (out_h && split) split_store(out_h + row * ldo + v * 4, C, y);
+      else if (out_h) *(f16x4*)(out_h + row * ldo + v * 4) = (f16x4){(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
       if (out_f) *(f32x4*)(out_f + row * ldo + v * 4) = y;
     }
+  }
+}
+
+// out[r, :] = split3(a[r, :] + b[(r*C + c) % n_b]) for contiguous f32 a [rows, C]; out f16 [rows, 3C]
+__global__ __launch_bounds__(256) void add_split_f16_kernel(const float* __restrict__ a,
+                                                            const float* __restrict__ b,
+                                                            f16* __restrict__ o, int64_t n4, int64_t nb4,
+                                                            int C) {
+  const int c4n = C >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 v = *(const f32x4*)(a + i * 4);
+    if (b) v += *(const f32x4*)(b + (i % nb4) * 4);
+    const int64_t row = i / c4n;
+    const int c = (int)(i - row * c4n) * 4;
+    split_store(o + row * 3 * C + c, C, v);
   }
 }
 
@@ -77,8 +112,9 @@ __global__ __launch_bounds__(256) void add_cvt_f16_kernel(const float* __restric
 extern "C" int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamma,
                                   const float* beta, float eps, const int32_t* gather,
                                   int32_t rows_out, int32_t C, void* out_f16, float* out_f32,
-                                  int64_t ldo, int32_t act, void* stream) {
+                                  int64_t ldo, int32_t act, int32_t split, void* stream) {
   INK_CHECK_ARG(x && (out_f16 || out_f32));
+  INK_CHECK_ARG(split == 0 || (split == 1 && out_f16 && !out_f32 && ldo >= 3 * (int64_t)C));
   INK_CHECK_ARG(act == INK_ACT_NONE || act == INK_ACT_GELU);
   INK_CHECK_ARG(rows_out > 0 && C > 0 && C % 4 == 0 && C <= 2048);
   INK_CHECK_ARG(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= C && ldo >= C);
@@ -87,7 +123,7 @@ extern "C" int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamm
   const int nv = (C / 4 + 63) / 64;
 #define INK_LN(NV)                                                                          \
   hipLaunchKernelGGL(layernorm_rows_kernel<NV>, grid, block, 0, s, x, ldx, gamma, beta, eps, \
-                     gather, rows_out, C, (f16*)out_f16, out_f32, ldo, act)
+                     gather, rows_out, C, (f16*)out_f16, out_f32, ldo, act, split)
   switch (nv) {
     case 1: INK_LN(1); break;
     case 2: INK_LN(2); break;
@@ -108,6 +144,17 @@ extern "C" int ink_add_cvt_f16(const float* a, const float* b, int64_t n_b, void
   const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(add_cvt_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b,
                      (f16*)out_f16, (float*)nullptr, n4, b ? n_b / 4 : 1);
+  return ink_launch_status();
+}
+
+extern "C" int ink_add_split_f16(const float* a, const float* b, int64_t n_b, void* out_f16, int64_t n,
+                                 int32_t C, void* stream) {
+  INK_CHECK_ARG(a && out_f16 && n > 0 && C > 0 && C % 4 == 0 && n % C == 0);
+  INK_CHECK_ARG(!b || (n_b > 0 && n_b % 4 == 0 && n % n_b == 0));
+  const int64_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(add_split_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b,
+                     (f16*)out_f16, n4, b ? n_b / 4 : 1, C);
   return ink_launch_status();
 }
 

@@ -39,6 +39,62 @@ def init_process_group(backend: str | None = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def launch_ranks(cmd: List[str], world: int, timeout_s: float | None = None, extra_env: Dict[str, str] | None = None):
+    """Start `world` fresh child processes of `cmd` (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set, rendezvous on 127.0.0.1 at a free port), wait for all of them, and return
+    (worst exit code, rank 0's stdout).  Used by `bench.py --gpus N` when it is started WITHOUT a launcher; the
+    parent must not have touched the GPU (children are new processes, nothing is exec'ed over a HIP-initialised
+    one).  If a rank dies, the others are terminated so that nobody waits forever in a collective."""
+    import socket
+    import subprocess
+    import tempfile
+    import time as _time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")               # a file, not a pipe: rank 0 can never block on its stdout
+    for r in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes on this driver)
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
+    t0 = _time.time()
+    rc = 0
+    pending = set(range(world))
+    try:
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0:
+                        rc = rc or code
+            if rc != 0:
+                break
+            if timeout_s is not None and _time.time() - t0 > timeout_s:
+                rc = 124
+                break
+            _time.sleep(0.05)
+    finally:
+        for r in pending:
+            procs[r].terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    out0.seek(0)
+    text = out0.read()
+    out0.close()
+    return rc, text
+
+
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     """Static round-robin: item i -> rank i % world."""
     return list(range(rank, n_items, world))

@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 from . import ops
+from ._lru import LRU
 
 F16, F32, I32 = torch.float16, torch.float32, torch.int32
 
@@ -204,6 +205,14 @@ class _Plan:
         self.valid_map = torch.where(valid, torch.arange(self.S), torch.full((self.S,), -1)).to(I32).to(dev)
 
 
+def clean_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """clean_state_dict (GD/util/misc.py:711-717): strip the DataParallel "module." prefix the shipped
+    GroundingDINO checkpoints carry (GD/util/inference.py:33-34 always applies it)."""
+    if any(k.startswith("module.") for k in sd):
+        return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    return sd
+
+
 class GDinoEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[GDinoConfig] = None,
                  device: str | torch.device = "cuda", encoded_text: Optional[torch.Tensor] = None,
@@ -213,9 +222,7 @@ class GDinoEngine:
         assert self.dev.type == "cuda", "the InkLayer detector runs on MI355X only"
         assert cfg.hidden_dim == 256 and cfg.nheads == 8 and cfg.num_feature_levels == 4 and cfg.n_points == 4
         assert all(cfg.embed_dim * 2 ** i // nh == 32 for i, nh in enumerate(cfg.num_heads))
-        sd, dev = state_dict, self.dev
-        if any(k.startswith("module.") for k in sd):       # clean_state_dict (GD/util/misc.py:711-717)
-            sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        sd, dev = clean_state_dict(state_dict), self.dev
         self.w: Dict[str, torch.Tensor] = {}
         w = self.w
 
@@ -326,9 +333,10 @@ class GDinoEngine:
         dt = torch.arange(128, dtype=torch.float32)
         w["dim_t"] = (10000 ** (2 * torch.div(dt, 2, rounding_mode="floor") / 128)).to(dev)
         # ---- text constants (image independent: caption is hard-coded "object.", InkLayer/detector/gdino.py:18)
+        self._graphs = LRU(self.graph_cache_size)
+        self._plans = LRU(self.plan_cache_size)
+        self._seen: Dict[Tuple[int, int, int], int] = {}
         self.set_text(encoded_text, token_ids)
-        self._graphs = {}
-        self._plans: Dict[Tuple[int, int, int], _Plan] = {}
 
     def set_text(self, encoded_text: Optional[torch.Tensor], token_ids: Sequence[int]) -> None:
         """encoded_text = feat_map(BERT(caption)) [T, 256] (groundingdino.py:277-279), a load-time constant."""
@@ -337,7 +345,8 @@ class GDinoEngine:
                              "(inklayer_amd.text_branch) or pass precomputed features")
         T = encoded_text.shape[0]
         assert T == len(token_ids) and T <= 4, "fusion kernel is specialised for captions of <= 4 tokens"
-        self._graphs = {}                              # captured forwards hold the old text tensors
+        self._graphs.clear()                           # captured forwards hold the old text tensors
+        self._seen.clear()
         self.T = T
         self.text0 = encoded_text.detach().to(self.dev, F32).contiguous()
         sm, pid = text_masks_and_position_ids(list(token_ids))
@@ -354,13 +363,23 @@ class GDinoEngine:
     # A replay does not overlap with eager work on another stream (measured: the two-stream pipeline got slower,
     # 16.6 -> 18.5 ms at batch 1), so InkLayerPipeline's overlapped mode passes allow_graph=False; the graph serves
     # the sequential use of the detector (run_ft_dino_on_sketch / detect), which is how the reference runs it.
+    # A capture costs two eager warm-ups + the capture (~3 forwards) and pins a private memory pool, so a size is
+    # captured only when it is seen the SECOND time, and at most `graph_cache_size` graphs (LRU) are kept: a directory
+    # of sketches with many aspect ratios runs eager and HBM stays bounded (tests/test_gdino_gpu.py).
     graph_max_batch = 1
+    graph_cache_size = 4
+    plan_cache_size = 8
 
     def _forward_graphed(self, images_u8: Sequence[torch.Tensor], h: int, w_: int):
         B = len(images_u8)
         key = (h, w_, B)
         g = self._graphs.get(key)
         if g is None:
+            self._seen[key] = self._seen.get(key, 0) + 1
+            if len(self._seen) > 4096:
+                self._seen.clear()
+            if self._seen[key] < 2:
+                return self._forward_eager(images_u8)
             static_in = [torch.empty_like(im) for im in images_u8]
             for dst, src in zip(static_in, images_u8):
                 dst.copy_(src)
@@ -373,18 +392,16 @@ class GDinoEngine:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self._forward_eager(static_in)
-            g = self._graphs[key] = (graph, static_in, out)
-        graph, static_in, out = g
+            g = (graph, static_in, out, self.plan(h, w_, B))   # the graph's kernels read its plan's buffers
+            self._graphs.put(key, g)
+        graph, static_in, out = g[:3]
         for dst, src in zip(static_in, images_u8):
             dst.copy_(src)
         graph.replay()
         return out[0].clone(), out[1].clone()            # the static outputs are overwritten by the next replay
 
     def plan(self, h: int, w: int, B: int) -> _Plan:
-        key = (h, w, B)
-        if key not in self._plans:
-            self._plans[key] = _Plan(self, h, w, B)
-        return self._plans[key]
+        return self._plans.get_or_make((h, w, B), lambda: _Plan(self, h, w, B))
 
     # ------------------------------------------------------------------ pieces
     def _mlp3(self, prefix: str, x16: torch.Tensor) -> torch.Tensor:

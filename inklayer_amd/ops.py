@@ -27,6 +27,16 @@ def set_gemm_trace(lst) -> None:
     _GEMM_TRACE = lst
 
 
+_ATTN_TRACE = None
+
+
+def set_attn_trace(lst) -> None:
+    """bench.py instrumentation: when `lst` is a list, every flash_attn() launch is bracketed by two HIP events on
+    the launch stream and (n_batch, n_heads, n_q, n_k, head_dim, bias_mode, rows_q, start, end) is appended."""
+    global _ATTN_TRACE
+    _ATTN_TRACE = lst
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
@@ -97,15 +107,20 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
 def layernorm_rows(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor],
                    eps: float, *, gather: Optional[torch.Tensor] = None,
                    out_dtype: torch.dtype = F16, out: Optional[torch.Tensor] = None,
-                   out2: Optional[torch.Tensor] = None, act: Optional[str] = None) -> torch.Tensor:
+                   out2: Optional[torch.Tensor] = None, act: Optional[str] = None,
+                   split: bool = False) -> torch.Tensor:
     """LayerNorm over the last dim of f32 x [R, C]; optional row gather (-1 -> zero row).
-    `out2` (the other of f16/f32, same shape/stride) receives a second copy in the same pass."""
+    `out2` (the other of f16/f32, same shape/stride) receives a second copy in the same pass.
+    split=True: the f16 output is a split-f16 GEMM operand [R, 3C] (see add_split_f16)."""
     assert x.dtype == F32 and x.dim() == 2 and x.stride(1) == 1
     Cdim = x.shape[1]
     rows = gather.numel() if gather is not None else x.shape[0]
+    wcols = 3 * Cdim if split else Cdim
+    if split:
+        assert out_dtype == F16 and out2 is None
     if out is None:
-        out = torch.empty((rows, Cdim), device=x.device, dtype=out_dtype)
-    assert out.shape == (rows, Cdim) and out.stride(1) == 1
+        out = torch.empty((rows, wcols), device=x.device, dtype=out_dtype)
+    assert out.shape == (rows, wcols) and out.stride(1) == 1
     oh = out.data_ptr() if out.dtype == F16 else None
     of = out.data_ptr() if out.dtype == F32 else None
     if out2 is not None:
@@ -117,7 +132,7 @@ def layernorm_rows(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optiona
     if gather is not None:
         assert gather.dtype == torch.int32
     check(_lib.lib().ink_layernorm_rows(x.data_ptr(), x.stride(0), _p(gamma), _p(beta), eps,
-                                        _p(gather), rows, Cdim, oh, of, out.stride(0), ACT[act],
+                                        _p(gather), rows, Cdim, oh, of, out.stride(0), ACT[act], int(split),
                                         _stream()), "ink_layernorm_rows")
     return out
 
@@ -136,6 +151,30 @@ def add_cvt_f16(a: torch.Tensor, b: Optional[torch.Tensor] = None,
     check(_lib.lib().ink_add_cvt_f16(a.data_ptr(), _p(b), nb, out.data_ptr(), a.numel(), _stream()),
           "ink_add_cvt_f16")
     return out
+
+
+def add_split_f16(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Split-f16 GEMM operand of v = a + b (contiguous f32 [R, C]; b a leading-dim broadcast): f16 [R, 3C] =
+    [hi | (v - hi) * 64 | hi / 64].  gemm() against `split_weight(W)` then yields v @ W.T at fp32-grade accuracy."""
+    assert a.dtype == F32 and a.is_contiguous() and a.dim() == 2
+    nb = 0
+    if b is not None:
+        assert b.dtype == F32 and b.is_contiguous() and a.numel() % b.numel() == 0
+        nb = b.numel()
+    R, Cn = a.shape
+    out = torch.empty((R, 3 * Cn), device=a.device, dtype=F16)
+    check(_lib.lib().ink_add_split_f16(a.data_ptr(), _p(b), nb, out.data_ptr(), a.numel(), Cn, _stream()),
+          "ink_add_split_f16")
+    return out
+
+
+def split_weight(w32: torch.Tensor) -> torch.Tensor:
+    """f32 [..., K] -> f16 [..., 3K] = [W_hi | W_hi / 64 | (W - W_hi) * 64]: the weight side of a split-f16 GEMM
+    (load-time re-layout, like the f16 cast of the other matrices)."""
+    w32 = w32.to(torch.float32)
+    hi = w32.to(F16)
+    lo = ((w32 - hi.to(torch.float32)) * 64.0).to(F16)
+    return torch.cat([hi, (hi.to(torch.float32) / 64.0).to(F16), lo], dim=-1).contiguous()
 
 
 def add_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -211,7 +250,14 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: in
         p.bias_mode, p.rel_h, p.rel_w = 1, rel_h.data_ptr(), rel_w.data_ptr()
     else:
         p.bias_mode = 0
-    check(_lib.lib().ink_flash_attn(C.byref(p), _stream()), "ink_flash_attn")
+    if _ATTN_TRACE is None:
+        check(_lib.lib().ink_flash_attn(C.byref(p), _stream()), "ink_flash_attn")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.lib().ink_flash_attn(C.byref(p), _stream()), "ink_flash_attn")
+        e1.record()
+        _ATTN_TRACE.append((n_batch, n_heads, n_q, n_k, head_dim, int(p.bias_mode), int(out.shape[0]), e0, e1))
     return out
 
 
@@ -263,15 +309,15 @@ def resize_bilinear_u8(image_u8: torch.Tensor, oh: int, ow: int, out: Optional[t
 
 
 def sam_patchify(image_u8: torch.Tensor, L: int, P: int, mean: Sequence[float],
-                 std: Sequence[float], chan_reverse: bool, out: torch.Tensor) -> torch.Tensor:
-    """uint8 HWC (h,w <= L) -> normalised, zero-padded f16 im2col [ (L/P)^2, 3*P*P ]."""
+                 std: Sequence[float], chan_reverse: bool, out: torch.Tensor, split: bool = False) -> torch.Tensor:
+    """uint8 HWC (h,w <= L) -> normalised, zero-padded f16 im2col [ (L/P)^2, 3*P*P ] (split: [.., 3*3*P*P])."""
     assert image_u8.dtype == torch.uint8 and image_u8.is_cuda and image_u8.is_contiguous()
     h, w, c = image_u8.shape
     assert c == 3 and out.dtype == F16 and out.is_contiguous()
-    assert out.numel() == (L // P) ** 2 * 3 * P * P
+    assert out.numel() == (L // P) ** 2 * 3 * P * P * (3 if split else 1)
     m = (C.c_float * 3)(*mean)
     s = (C.c_float * 3)(*std)
-    check(_lib.lib().ink_sam_patchify(image_u8.data_ptr(), h, w, L, P, m, s, int(chan_reverse),
+    check(_lib.lib().ink_sam_patchify(image_u8.data_ptr(), h, w, L, P, m, s, int(chan_reverse), int(split),
                                       out.data_ptr(), _stream()), "ink_sam_patchify")
     return out
 
@@ -427,29 +473,40 @@ def biattn_fusion(qv16: torch.Tensor, kl16: torch.Tensor, B: int, S: int, T: int
 
 
 def attn_fewkeys(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, B: int, n_heads: int, head_dim: int,
-                 scale: float, blocked: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 scale: float, blocked: Optional[torch.Tensor] = None, n_q: Optional[int] = None,
+                 q_batch_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Attention against n_k <= 16 keys per batch entry; q/k/v/out are all f16 or all f32 rows (f32 math either
+    way).  q_batch_rows: first q row of each batch entry (then n_q must be given)."""
+    io = q.dtype
     for t in (q, k, v):
-        assert t.dtype == F16 and t.dim() == 2 and t.stride(1) == 1
-    n_q, n_k = q.shape[0] // B, k.shape[0] // B
-    out = torch.empty((B * n_q, n_heads * head_dim), device=q.device, dtype=F16)
+        assert t.dtype == io and io in (F16, F32) and t.dim() == 2 and t.stride(1) == 1
+    if n_q is None:
+        n_q = q.shape[0] // B
+    n_k = k.shape[0] // B
+    out = torch.empty((B * n_q, n_heads * head_dim), device=q.device, dtype=io)
     if blocked is not None:
         assert blocked.dtype == torch.uint8 and blocked.is_contiguous() and blocked.shape == (n_q, n_k)
+    if q_batch_rows is not None:
+        assert q_batch_rows.dtype == torch.int32 and q_batch_rows.numel() == B and q_batch_rows.is_cuda
     check(_lib.lib().ink_attn_fewkeys(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
                                       v.stride(0), B, n_q, n_k, n_heads, head_dim, scale, _p(blocked),
-                                      out.data_ptr(), out.stride(0), _stream()), "ink_attn_fewkeys")
+                                      _p(q_batch_rows), int(io == F32), out.data_ptr(), out.stride(0), _stream()),
+          "ink_attn_fewkeys")
     return out
 
 
 def attn_fewq(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: int, n_heads: int, head_dim: int,
               scale: float, n_q: int, n_k: int, q_batch_rows: Optional[torch.Tensor] = None,
               kv_batch_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Few queries (<= 8) against many keys; same row conventions as flash_attn."""
+    """Few queries (<= 8) against many keys; same row conventions as flash_attn.  q/k/v/out all f16 or all f32."""
+    io = q.dtype
     for t in (q, k, v):
-        assert t.dtype == F16 and t.dim() == 2 and t.stride(1) == 1
-    out = torch.empty((n_batch * n_q, n_heads * head_dim), device=q.device, dtype=F16)
+        assert t.dtype == io and io in (F16, F32) and t.dim() == 2 and t.stride(1) == 1
+    out = torch.empty((n_batch * n_q, n_heads * head_dim), device=q.device, dtype=io)
     check(_lib.lib().ink_attn_fewq(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                    n_batch, n_q, n_k, n_heads, head_dim, scale, _p(q_batch_rows),
-                                   _p(kv_batch_rows), out.data_ptr(), out.stride(0), _stream()), "ink_attn_fewq")
+                                   _p(kv_batch_rows), int(io == F32), out.data_ptr(), out.stride(0), _stream()),
+          "ink_attn_fewq")
     return out
 
 

@@ -21,6 +21,15 @@ from .ops import sam_postprocess as ops_sam_postprocess
 
 
 @dataclass
+class HostTicket:
+    """One in-flight host-to-host batch (InkLayerPipeline.submit_host / collect_host)."""
+    slot: int
+    done: "torch.cuda.Event"
+    dets: list                         # per image: (xyxy float64 [n,4], scores [n], pixel boxes [n,4])
+    views: list                        # per image: (offset into the slot's pinned mask buffer, n, H, W)
+
+
+@dataclass
 class SketchResult:
     boxes_xyxy_norm: np.ndarray       # [n,4] float64, normalised (the detector plugin's "bboxes")
     scores: np.ndarray                # [n]
@@ -70,21 +79,104 @@ class InkLayerPipeline:
         self.overlap = overlap
         self.s_det = torch.cuda.Stream(device=self.dev) if overlap else None
         self.s_seg = torch.cuda.Stream(device=self.dev) if overlap else None
+        # host <-> device traffic of the host-to-host entry points rides its own stream: the upload of batch i+1 and
+        # the mask download of batch i run under the compute of the neighbouring batch (two pinned slots)
+        self.s_copy = torch.cuda.Stream(device=self.dev)
+        self._host_in: List[Optional[torch.Tensor]] = [None, None]
+        self._host_out: List[Optional[torch.Tensor]] = [None, None]
+        self._slot_free: List[Optional[torch.cuda.Event]] = [None, None]
+        self._next_slot = 0
 
     def upload(self, images_rgb: Sequence[np.ndarray]) -> List[torch.Tensor]:
         """Decoded RGB sketches (HWC uint8, host) -> device, one transfer each.  Everything after this point -
         both resizes, normalisation, patchify - runs on the GPU."""
-        return [torch.from_numpy(np.ascontiguousarray(im)).to(self.dev, non_blocking=True) for im in images_rgb]
+        out = []
+        for im in images_rgb:
+            a = np.ascontiguousarray(im)
+            if not a.flags.writeable:
+                a = a.copy()
+            out.append(torch.from_numpy(a).to(self.dev, non_blocking=True))
+        return out
+
+    # ------------------------------------------------------------------ host-to-host (SURVEY §8d metric)
+    @staticmethod
+    def pinned_like(images_rgb: Sequence[np.ndarray]) -> List[torch.Tensor]:
+        """Copies of decoded sketches in page-locked host memory (where an image decoder of a serving process would
+        put them): the source of submit_host's asynchronous uploads."""
+        return [torch.from_numpy(np.array(im, copy=True)).pin_memory() for im in images_rgb]
+
+    @torch.no_grad()
+    def submit_host(self, images_pinned: Sequence[torch.Tensor], top_n: Optional[int] = None) -> HostTicket:
+        """The metric's unit of work, host memory to host memory: decoded RGB u8 sketches (pinned host tensors) ->
+        boxes + uint8 0/1 masks [n, H, W] in pinned host memory (the reference returns exactly that: one numpy bool
+        array per box, InkLayer/segmentor/sam.py:39-41; 1 byte per pixel, no bit-packing).  Returns as soon as the
+        work is queued - the only host wait inside is the detector's boxes - so the caller can submit batch i+1
+        before collecting batch i: the mask download of i (134 MB for 8 x 16 masks of 1024^2) and the upload of
+        i+1 (25 MB) then overlap with compute.  Two slots: collect a ticket before submitting two more."""
+        slot = self._next_slot
+        self._next_slot ^= 1
+        cur = torch.cuda.current_stream(self.dev)
+        if self._slot_free[slot] is not None:
+            self._slot_free[slot].synchronize()           # the download that last used this slot has finished
+        with torch.cuda.stream(self.s_copy):
+            raw = [t.to(self.dev, non_blocking=True) for t in images_pinned]
+            up = torch.cuda.Event()
+            up.record(self.s_copy)
+        cur.wait_event(up)
+        for r in raw:
+            r.record_stream(cur)
+        res = self.run_uploaded(raw, top_n=top_n)
+        total = sum(int(r.masks.numel()) for r in res)
+        if self._host_out[slot] is None or self._host_out[slot].numel() < total:
+            self._host_out[slot] = torch.empty(max(total, 1), dtype=torch.uint8, pin_memory=True)
+        hbuf = self._host_out[slot]
+        self.s_copy.wait_stream(cur)
+        views, off = [], 0
+        with torch.cuda.stream(self.s_copy):
+            # masks of consecutive images that share one postprocess launch are one contiguous device tensor:
+            # copy run by run (usually ONE transfer per batch)
+            i = 0
+            while i < len(res):
+                j, base = i, res[i].masks
+                n_el = int(base.numel())
+                while (j + 1 < len(res) and res[j + 1].masks.numel() > 0 and n_el > 0
+                       and res[j + 1].masks.data_ptr() == base.data_ptr() + n_el
+                       and res[j + 1].masks.untyped_storage().data_ptr() == base.untyped_storage().data_ptr()):
+                    j += 1
+                    n_el += int(res[j].masks.numel())
+                if n_el > 0:
+                    src = torch.as_strided(base, (n_el,), (1,))
+                    src.record_stream(self.s_copy)
+                    hbuf[off:off + n_el].copy_(src, non_blocking=True)
+                for k in range(i, j + 1):
+                    m = res[k].masks
+                    views.append((off, int(m.shape[0]), int(m.shape[1]), int(m.shape[2])))
+                    off += int(m.numel())
+                i = j + 1
+            done = torch.cuda.Event()
+            done.record(self.s_copy)
+        self._slot_free[slot] = done
+        return HostTicket(slot, done, [(r.boxes_xyxy_norm, r.scores, r.boxes_pixel) for r in res], views)
+
+    def collect_host(self, t: HostTicket):
+        """Wait for a ticket's masks to be in host memory.  -> per image (boxes_xyxy_norm, scores, boxes_pixel,
+        masks uint8 numpy [n, H, W]); the mask arrays are views of the slot's pinned buffer, valid until the
+        slot is reused (two submits later)."""
+        t.done.synchronize()
+        hb = self._host_out[t.slot].numpy()
+        return [(d[0], d[1], d[2], hb[off:off + n * h * w].reshape(n, h, w))
+                for d, (off, n, h, w) in zip(t.dets, t.views)]
 
     def preprocess(self, raw: Sequence[torch.Tensor]):
-        """GPU side of load_image / ResizeLongestSide (Pillow-exact bilinear, `ink_resize_bilinear_u8`), plus
-        SAM's channel quirk (InkLayer/segmentor/sam.py:24-26 feeds the encoder channel-reversed pixels)."""
+        """GPU side of load_image / ResizeLongestSide (Pillow-exact bilinear, `ink_resize_bilinear_u8`).  SAM's
+        channel quirk (InkLayer/segmentor/sam.py:24-26 feeds the encoder channel-reversed pixels) is applied by the
+        patchify kernel (chan_reverse), not by a copy."""
         det_in, sam_in, sizes = [], [], []
         L = self.seg.cfg.img_size
         for im in raw:
             d, s_ = gpu_preprocess(im, L)
             det_in.append(d)
-            sam_in.append(s_.flip(-1).contiguous())
+            sam_in.append(s_)              # RGB order; the channel reversal happens inside ink_sam_patchify
             sizes.append(((int(im.shape[0]), int(im.shape[1])), (int(s_.shape[0]), int(s_.shape[1]))))
         return det_in, sam_in, sizes
 
@@ -98,11 +190,10 @@ class InkLayerPipeline:
         return self.run_prepared(*self.preprocess(raw), top_n=top_n)
 
     @torch.no_grad()
-    def run_prepared(self, det_in, sam_in, sizes, top_n: Optional[int] = None,
-                     defer_sync: bool = False) -> List[SketchResult]:
-        """defer_sync=True (needs overlap): the caller's stream is NOT made to wait for the results; consecutive
-        batches then pipeline (batch i+1's detector runs under batch i's encoder/decoder).  The caller must call
-        `synchronize()` (or wait on `s_seg`) before touching the returned masks."""
+    def run_prepared(self, det_in, sam_in, sizes, top_n: Optional[int] = None) -> List[SketchResult]:
+        """Detector and SAM encoder on two HIP streams, joined before the mask decoder; results are ready on the
+        caller's stream.  (Letting consecutive batches overlap as well was measured slower - one batch already
+        saturates the GPU - and was removed.)"""
         if self.overlap:
             cur = torch.cuda.current_stream(self.dev)
             self.s_det.wait_stream(cur)
@@ -115,30 +206,26 @@ class InkLayerPipeline:
                 ev = torch.cuda.Event()
                 ev.record(self.s_det)
             with torch.cuda.stream(self.s_seg):
-                emb = self.seg.encode(sam_in)
+                emb = self.seg.encode(sam_in, chan_reverse=True)
             ev.synchronize()                               # host needs the boxes; the encoder keeps running
             dets = self.det.postprocess(host, top_n=top_n)
             stream_ctx = torch.cuda.stream(self.s_seg)
         else:
             dets = self.det.detect(det_in, top_n=top_n)
-            emb = self.seg.encode(sam_in)
+            emb = self.seg.encode(sam_in, chan_reverse=True)
             stream_ctx = _NullCtx()
         with stream_ctx:
             out = self._decode_all(dets, emb, sizes)
-        if self.overlap and not defer_sync:
-            cur = torch.cuda.current_stream(self.dev)
-            cur.wait_stream(self.s_seg)
-            cur.wait_stream(self.s_det)
-            for r in out:                                  # results are consumed on the caller's stream
-                r.masks.record_stream(cur)
-        return out
-
-    def synchronize(self) -> None:
-        """Join both pipeline streams into the caller's stream (after a run of defer_sync=True batches)."""
         if self.overlap:
             cur = torch.cuda.current_stream(self.dev)
             cur.wait_stream(self.s_seg)
             cur.wait_stream(self.s_det)
+            for t in list(det_in) + list(sam_in):          # allocated on the caller's stream, read on s_det / s_seg
+                t.record_stream(self.s_det)
+                t.record_stream(self.s_seg)
+            for r in out:                                  # allocated on s_seg, consumed on the caller's stream
+                r.masks.record_stream(cur)
+        return out
 
     def _decode_all(self, dets, emb, sizes) -> List[SketchResult]:
         L = self.seg.cfg.img_size

@@ -14,6 +14,8 @@ from typing import Dict, Tuple
 import numpy as np
 import torch
 
+from ._lru import LRU
+
 PRECISION_BITS = 32 - 8 - 2
 
 
@@ -69,11 +71,9 @@ class ResizePlan:
         self.tmp = torch.empty((h, ow, 3), device=dev, dtype=torch.uint8) if (ow != w and oh != h) else None
 
 
-_PLANS: Dict[Tuple, ResizePlan] = {}
+_PLANS = LRU(32)      # (source size, target size) pairs seen recently; a plan is a few hundred KB of tables
 
 
 def plan_for(h: int, w: int, oh: int, ow: int, device) -> ResizePlan:
     key = (h, w, oh, ow, str(device))
-    if key not in _PLANS:
-        _PLANS[key] = ResizePlan(h, w, oh, ow, device)
-    return _PLANS[key]
+    return _PLANS.get_or_make(key, lambda: ResizePlan(h, w, oh, ow, device))

@@ -14,7 +14,11 @@ Design (MI355X-first, not a translation of the nn.Module tree):
   * attention never materialises scores; the decomposed rel-pos bias rides inside the MFMA
     accumulator (attention.hip);
   * ConvTranspose2d k2s2 = a [C -> 4*C'] projection whose pixel shuffle is deferred to the
-    final mask-logit kernel; the two bilinear resizes + threshold are one kernel.
+    final mask-logit kernel; the two bilinear resizes + threshold are one kernel;
+  * precision: the 32 ViT-H blocks run on plain f16 operands; the neck, the prompt / mask
+    decoder, the upscaler and the hyper-network - 1 % of the FLOPs, but the layers whose f16 rounding dominated
+    the mask error - run on SPLIT-f16 operands (hi + lo, three MFMA products per term, fp32-grade) with f32
+    activations and f32-I/O attention, because the reference thresholds fp32 logits at exactly 0.
 No torch compute ops are used on the hot path — torch supplies memory, streams, copies.
 """
 from __future__ import annotations
@@ -82,9 +86,12 @@ class SamEngine:
     """Weights packed for the HIP kernels + preallocated activations for up to `max_batch` images."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[SamConfig] = None,
-                 device: str | torch.device = "cuda", max_batch: int = 1):
+                 device: str | torch.device = "cuda", max_batch: int = 1, precise_tail: bool = True):
+        """precise_tail=True (the product setting): neck + decoder on split-f16 operands.  False keeps the plain
+        f16 tail of round 1 (faster by a few %, mask IoU 0.998 instead of >= 0.999; kept for A/B measurements)."""
         cfg = cfg or SamConfig()
         self.cfg, self.dev = cfg, torch.device(device)
+        self.precise_tail = bool(precise_tail)
         assert self.dev.type == "cuda", "the InkLayer segmentor runs on MI355X only"
         D, g = cfg.embed_dim, cfg.grid
         assert D // cfg.num_heads == 80 and g == 64 and cfg.window_size == 14, \
@@ -183,7 +190,49 @@ class SamEngine:
             w[f"iou{j}.b"] = f(f"mask_decoder.iou_prediction_head.layers.{j}.bias")
         # the last hyper layer has N = 32 outputs, the iou head N = 4: both fine for the GEMM (N % 4)
 
+        if self.precise_tail:
+            self._pack_split(sd)
         self._alloc(max_batch)
+
+    def _pack_split(self, sd) -> None:
+        """Split-f16 weight copies [N, 3K] (ops.split_weight) of the neck / decoder matrices, keyed '<name>.ws'."""
+        cfg, w, dev = self.cfg, self.w, self.dev
+        E, D = cfg.prompt_embed_dim, cfg.embed_dim
+
+        def m(name):
+            return sd[name].detach().to(dev, torch.float32)
+
+        P = cfg.patch_size
+        w["pe.ws"] = ops.split_weight(m("image_encoder.patch_embed.proj.weight").reshape(D, 3 * P * P))
+        w["neck0.ws"] = ops.split_weight(m("image_encoder.neck.0.weight").reshape(E, D))
+        # 3x3 conv as [co][(ky,kx)][ci]: the im2col of a split activation row is (ky,kx) x [hi | lo | hi/64]
+        w["neck2.ws"] = ops.split_weight(m("image_encoder.neck.2.weight").permute(0, 2, 3, 1).reshape(E, 9, E)) \
+            .reshape(E, 27 * E).contiguous()
+        t = "mask_decoder.transformer."
+
+        def attn(dst, src):
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                w[f"{dst}.{n}.ws"] = ops.split_weight(m(f"{src}.{n}.weight"))
+
+        for i in range(cfg.dec_depth):
+            p = f"{t}layers.{i}."
+            for a_, b_ in ((f"d{i}.self", p + "self_attn"), (f"d{i}.t2i", p + "cross_attn_token_to_image"),
+                           (f"d{i}.i2t", p + "cross_attn_image_to_token")):
+                attn(a_, b_)
+            d = f"d{i}.self"
+            if i == 0:
+                w[d + ".qkv.ws"] = torch.cat([w[f"{d}.{n}.ws"] for n in ("q_proj", "k_proj", "v_proj")]).contiguous()
+            else:
+                w[d + ".qk.ws"] = torch.cat([w[f"{d}.{n}.ws"] for n in ("q_proj", "k_proj")]).contiguous()
+            w[f"d{i}.lin1.ws"] = ops.split_weight(m(p + "mlp.lin1.weight"))
+            w[f"d{i}.lin2.ws"] = ops.split_weight(m(p + "mlp.lin2.weight"))
+        attn("dfin", t + "final_attn_token_to_image")
+        u = "mask_decoder.output_upscaling."
+        w["up0.ws"] = ops.split_weight(m(u + "0.weight").permute(2, 3, 1, 0).reshape(4 * (E // 4), E))
+        w["up3.ws"] = ops.split_weight(m(u + "3.weight").permute(2, 3, 1, 0).reshape(4 * (E // 8), E // 4))
+        for j in range(3):
+            w[f"hyp{j}.ws"] = ops.split_weight(m(f"mask_decoder.output_hypernetworks_mlps.0.layers.{j}.weight"))
+            w[f"iou{j}.ws"] = ops.split_weight(m(f"mask_decoder.iou_prediction_head.layers.{j}.weight"))
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, B: int) -> None:
@@ -204,7 +253,7 @@ class SamEngine:
         self.win_map = m.to(torch.int32).to(dev)
         P = cfg.patch_size
         e = lambda *s, dt=F16: torch.empty(s, device=dev, dtype=dt)
-        self.buf_patches = e(B * T, 3 * P * P)
+        self.buf_patches = e(B * T, 3 * P * P * (3 if self.precise_tail else 1))
         self.x = e(B * T, D, dt=F32)
         self.y = e(B * T, D)
         self.qkv = e(B * T, 3 * D)
@@ -227,10 +276,12 @@ class SamEngine:
         H, Mw = cfg.num_heads, self.Mw
         x = self.x[:B * T]
         for b, img in enumerate(images_u8):
+            # the patch embedding runs on split-f16 operands too: its rounding error would sit in the residual stream
+            # of all 32 blocks (measured: the largest single contribution to the mask error)
             ops.sam_patchify(img, cfg.img_size, cfg.patch_size, cfg.pixel_mean, cfg.pixel_std,
-                             chan_reverse, self.buf_patches[b * T:(b + 1) * T])
-            ops.gemm(self.buf_patches[b * T:(b + 1) * T], w["pe.w"], w["pe.b"], residual=w["pos"],
-                     out=x[b * T:(b + 1) * T])
+                             chan_reverse, self.buf_patches[b * T:(b + 1) * T], split=self.precise_tail)
+            ops.gemm(self.buf_patches[b * T:(b + 1) * T], w["pe.ws" if self.precise_tail else "pe.w"], w["pe.b"],
+                     residual=w["pos"], out=x[b * T:(b + 1) * T])
         nblk = cfg.depth if upto is None else upto
         for i in range(nblk):
             k = f"b{i}."
@@ -270,6 +321,12 @@ class SamEngine:
         if upto is not None:
             return x.view(B, T, D)
         # neck (image_encoder.py:88-104): 1x1 conv -> LN2d -> 3x3 conv -> LN2d, all on NHWC tokens
+        if self.precise_tail:
+            n0 = ops.gemm(ops.add_split_f16(x), w["neck0.ws"])
+            n1 = ops.layernorm_rows(n0, w["neck1.w"], w["neck1.b"], 1e-6, split=True)       # [B*T, 3E]
+            n2 = ops.gemm(ops.im2col3x3(n1, B, cfg.grid, cfg.grid), w["neck2.ws"])
+            emb = ops.layernorm_rows(n2, w["neck3.w"], w["neck3.b"], 1e-6, out_dtype=F32)
+            return emb.view(B, T, cfg.prompt_embed_dim)
         xh = ops.add_cvt_f16(x, out=self.y[:B * T])
         n0 = ops.gemm(xh, w["neck0.w"])
         n1 = ops.layernorm_rows(n0, w["neck1.w"], w["neck1.b"], 1e-6)
@@ -314,6 +371,8 @@ class SamEngine:
         one image at a time; batching only changes which rows share a launch).  emb [B, 4096, 256] f32,
         boxes [N, 4] xyxy in the resized-input frame (host), img_of_box[i] = image of box i.
         -> (low-res logits [N, 256, 256] f32, iou [N, 1] f32)."""
+        if self.precise_tail:
+            return self._decode_low_res_split(emb, boxes, img_of_box)
         cfg, w, T, dev = self.cfg, self.w, self.T, self.dev
         E, L, g = cfg.prompt_embed_dim, cfg.img_size, cfg.grid
         B = emb.shape[0]
@@ -394,6 +453,97 @@ class SamEngine:
         u0 = ops.gemm(ops.add_cvt_f16(keys), w["up0.w"], w["up0.b"])             # [n*T, 4*64]
         u1 = ops.layernorm_rows(u0.view(n * T * 4, E // 4), w["up1.w"], w["up1.b"], 1e-6, act="gelu")
         u2 = ops.gemm(u1, w["up3.w"], w["up3.b"], act="gelu")                     # [n*T*4, 4*32]
+        low = ops.sam_mask_logits(u2, hyper.contiguous(), n, g)                   # [n, 256, 256]
+        return low, iou
+
+    def _decode_low_res_split(self, emb: torch.Tensor, boxes: torch.Tensor, img_of_box: Sequence[int]):
+        """decode_low_res on split-f16 operands: every activation stays f32, every projection multiplies a
+        [hi | lo*64 | hi/64] operand (ops.add_split_f16 / layernorm_rows(split=True)) with a '.ws' weight, the three
+        attentions read and write f32 rows.  Same structure as the reference (mask_decoder.py:112-149,
+        transformer.py:62-106,151-182)."""
+        cfg, w, T, dev = self.cfg, self.w, self.T, self.dev
+        E, L, g = cfg.prompt_embed_dim, cfg.img_size, cfg.grid
+        B = emb.shape[0]
+        n = boxes.shape[0]
+        assert n > 0 and len(img_of_box) == n
+        NT, Hh = 5 + 2, cfg.dec_heads
+        SP = ops.add_split_f16
+
+        def lin(x_split, name, bias=True, **kw):
+            return ops.gemm(x_split, w[name + ".ws"], w[name + ".b"] if bias else None, **kw)
+
+        coords = _to_dev_async((boxes + 0.5).reshape(-1, 2) / float(L), dev)
+        sparse = ops.sam_pe_encode(coords, w["gauss"], add=w["corner"])           # [2n, E]
+        tokens = torch.empty((n, NT, E), device=dev, dtype=F32)
+        tokens[:, :5] = w["out_tok"]
+        tokens[:, 5:] = sparse.view(n, 2, E)
+        qpe = tokens.view(n * NT, E)
+        iob = torch.as_tensor(list(img_of_box), dtype=torch.int64)
+        img_rows = _to_dev_async((iob * T).to(torch.int32), dev)
+        iob_dev = _to_dev_async(iob, dev)
+        keys = ops.add_f32(emb.reshape(B * T, E).contiguous(), w["no_mask"])      # [B*T, E], shared per image
+        kpe = self.dense_pe
+        shared = True                                       # keys still one copy per IMAGE (layer 0)
+        queries = qpe
+        sc32, sc16 = 1.0 / math.sqrt(32), 1.0 / math.sqrt(16)
+
+        def t2i(name, queries, keys_pe_s, keys_s, residual):
+            q = lin(SP(queries, qpe), name + ".q_proj")
+            k = lin(keys_pe_s, name + ".k_proj")
+            v = lin(keys_s, name + ".v_proj")
+            a = ops.attn_fewq(q, k, v, n_batch=n, n_heads=Hh, head_dim=16, scale=sc16, n_q=NT, n_k=T,
+                              kv_batch_rows=img_rows if shared else None)
+            return lin(SP(a), name + ".out_proj", residual=residual)
+
+        for i in range(cfg.dec_depth):
+            d = f"d{i}"
+            # (1) token self-attention (layer 0: no positional add, output replaces the queries)
+            if i == 0:
+                qkv = ops.gemm(SP(queries), w[d + ".self.qkv.ws"], w[d + ".self.qkv.b"])
+                a = ops.attn_fewkeys(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B=n, n_heads=Hh, head_dim=32,
+                                     scale=sc32)
+                queries = lin(SP(a), d + ".self.out_proj")
+            else:
+                qk = ops.gemm(SP(queries, qpe), w[d + ".self.qk.ws"], w[d + ".self.qk.b"])
+                v = lin(SP(queries), d + ".self.v_proj")
+                a = ops.attn_fewkeys(qk[:, :E], qk[:, E:], v, B=n, n_heads=Hh, head_dim=32, scale=sc32)
+                queries = lin(SP(a), d + ".self.out_proj", residual=queries)
+            queries = ops.layernorm_rows(queries, w[d + ".norm1.w"], w[d + ".norm1.b"], 1e-5, out_dtype=F32)
+            # (2) tokens -> image
+            kps, ks = SP(keys, kpe), SP(keys)
+            queries = ops.layernorm_rows(t2i(d + ".t2i", queries, kps, ks, queries),
+                                         w[d + ".norm2.w"], w[d + ".norm2.b"], 1e-5, out_dtype=F32)
+            # (3) token MLP
+            hmid = lin(SP(queries), d + ".lin1", act="relu")
+            queries = ops.layernorm_rows(lin(SP(hmid), d + ".lin2", residual=queries),
+                                         w[d + ".norm3.w"], w[d + ".norm3.b"], 1e-5, out_dtype=F32)
+            # (4) image -> tokens: q = keys + key_pe (the operand of step 2), k = queries + qpe, v = queries
+            iq = lin(kps, d + ".i2t.q_proj")                                     # [B*T or n*T, 128]
+            ik = lin(SP(queries, qpe), d + ".i2t.k_proj")
+            iv = lin(SP(queries), d + ".i2t.v_proj")
+            a = ops.attn_fewkeys(iq, ik, iv, B=n, n_heads=Hh, head_dim=16, scale=sc16, n_q=T,
+                                 q_batch_rows=img_rows if shared else None)       # [n*T, 128]
+            if shared:
+                # per-box copy of the image keys (repeat_interleave of mask_decoder.py:124; a pure memory copy)
+                keys = keys.view(B, T * E).index_select(0, iob_dev).view(n * T, E)
+                shared = False
+            keys = ops.layernorm_rows(lin(SP(a), d + ".i2t.out_proj", residual=keys),
+                                      w[d + ".norm4.w"], w[d + ".norm4.b"], 1e-5, out_dtype=F32)
+        ks = SP(keys)
+        queries = ops.layernorm_rows(t2i("dfin", queries, SP(keys, kpe), ks, queries),
+                                     w["dfin.norm.w"], w["dfin.norm.b"], 1e-5, out_dtype=F32)
+        hs = queries.view(n, NT, E)
+
+        def mlp3(prefix: str, x: torch.Tensor) -> torch.Tensor:
+            a = lin(SP(x), prefix + "0", act="relu")
+            a = lin(SP(a), prefix + "1", act="relu")
+            return lin(SP(a), prefix + "2")
+
+        hyper = mlp3("hyp", hs[:, 1].contiguous())          # mask token 0 -> [n, 32]
+        iou = mlp3("iou", hs[:, 0].contiguous())[:, :1]     # iou token -> [n, 4] -> mask 0
+        u0 = lin(ks, "up0")                                                      # [n*T, 4*64]
+        u1 = ops.layernorm_rows(u0.view(n * T * 4, E // 4), w["up1.w"], w["up1.b"], 1e-6, act="gelu", split=True)
+        u2 = lin(u1, "up3", act="gelu")                                          # [n*T*4, 4*32]
         low = ops.sam_mask_logits(u2, hyper.contiguous(), n, g)                   # [n, 256, 256]
         return low, iou
 

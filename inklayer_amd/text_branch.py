@@ -5,11 +5,12 @@ InkLayer always prompts with the caption "object" (InkLayer/detector/gdino.py:18
 checkpoint is loaded (plain torch on the host: ~0.7 GFLOP, never on the hot path) and handed to the
 detector engine as a [n_tokens, 256] tensor.
 
-PARITY UNPINNED: bert-base-uncased (weights and vocabulary) is not available offline and the
-reference's BertModelWarper does not construct against the installed transformers, so
-this restatement of BertModelWarper.forward (GD/.../bertwarper.py:31-166: HF BertModel with a 3-D
-block attention mask and explicit position ids) could only be checked for shape/finite-ness.
-The token ids of the caption are DATA here ([CLS]=101, "object"=4874 (unverified), "."=1012, [SEP]=102).
+Parity: this restatement of BertModelWarper.forward (GD/.../bertwarper.py:31-166: HF BertModel with the
+sub-sentence block attention mask and explicit position ids) is pinned against `transformers.BertModel` itself on
+seeded random weights of the same architecture (tests/test_text_branch_cpu.py, max abs diff ~1e-6).  The
+bert-base-uncased WEIGHTS and VOCABULARY are not available offline: they arrive with the GroundingDINO checkpoint
+(`bert.*` keys), and the token ids of the caption are DATA here ([CLS]=101, "object"=4874 (unverifiable offline),
+"."=1012, [SEP]=102).
 """
 from __future__ import annotations
 

@@ -237,14 +237,18 @@ def vit_block(sd: SD, cfg: SamConfig, i: int, x: torch.Tensor) -> torch.Tensor:
     return x + y
 
 
-def image_encoder(sd: SD, cfg: SamConfig, x: torch.Tensor, upto: int | None = None) -> torch.Tensor:
+def image_encoder(sd: SD, cfg: SamConfig, x: torch.Tensor, upto: int | None = None,
+                  taps: Dict[int, torch.Tensor] | None = None) -> torch.Tensor:
     """ImageEncoderViT.forward (image_encoder.py:106-116): [B,3,L,L] -> [B,E,L/16,L/16].
-    `upto` = stop after that many blocks and return the NHWC token map (stage-level checks)."""
+    `upto` = stop after that many blocks and return the NHWC token map (stage-level checks);
+    `taps` = {n_blocks: None} is filled with the NHWC token map after that many blocks (full-depth error growth)."""
     x = F.conv2d(x, sd["image_encoder.patch_embed.proj.weight"],
                  sd["image_encoder.patch_embed.proj.bias"], stride=cfg.patch_size)
     x = x.permute(0, 2, 3, 1) + sd["image_encoder.pos_embed"]
     for i in range(cfg.depth if upto is None else upto):
         x = vit_block(sd, cfg, i, x)
+        if taps is not None and (i + 1) in taps:
+            taps[i + 1] = x.clone()
     if upto is not None:
         return x
     x = x.permute(0, 3, 1, 2)
@@ -417,7 +421,7 @@ def mask_decoder(sd: SD, cfg: SamConfig, image_emb: torch.Tensor, image_pe: torc
 # ----------------------------------------------------------------------------------------
 @torch.no_grad()
 def run_sam(sd: SD, cfg: SamConfig, image_rgb: np.ndarray, boxes_xyxy: torch.Tensor,
-            return_logits: bool = False):
+            return_logits: bool = False, taps: Dict[int, torch.Tensor] | None = None):
     """image_rgb: HxWx3 uint8 as np.array(PIL RGB); boxes in original pixel coords.
     Reproduces the reference's channel quirk: run_SAM passes the RGB array through
     COLOR_BGR2RGB (a channel reversal) and then declares it "RGB" (sam.py:24-26)."""
@@ -426,7 +430,9 @@ def run_sam(sd: SD, cfg: SamConfig, image_rgb: np.ndarray, boxes_xyxy: torch.Ten
     rs = apply_image(img, cfg.img_size)
     x = torch.as_tensor(rs).permute(2, 0, 1).contiguous()
     ih, iw = x.shape[-2:]
-    emb = image_encoder(sd, cfg, preprocess(cfg, x)[None])
+    emb = image_encoder(sd, cfg, preprocess(cfg, x)[None], taps=taps)
+    if taps is not None:
+        taps[-1] = emb
     tb = apply_boxes(boxes_xyxy, (oh, ow), cfg.img_size)
     sparse = embed_boxes(sd, cfg, tb)
     low, iou = mask_decoder(sd, cfg, emb, dense_pe(sd, cfg), sparse)

@@ -22,7 +22,8 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 4
     for s in syms:
         assert hasattr(l, s), f"{s} declared in inklayer_hip.h but not exported"
-    assert l.ink_abi_version() == 2
+    hdr = (ROOT / "include" / "inklayer_hip.h").read_text()
+    assert l.ink_abi_version() == int(re.search(r"#define\s+INK_ABI_VERSION\s+(\d+)", hdr).group(1))
 
 
 def test_python_binding_covers_header():
@@ -41,7 +42,8 @@ def test_bad_arguments_are_rejected_without_launch():
     p.lda = p.ldw = 24
     p.ldc = 8
     assert l.ink_gemm_f16(ctypes.byref(p), None) == 1
-    assert l.ink_layernorm_rows(None, 0, None, None, 1e-6, None, 1, 4, None, None, 4, 0, None) == 1
+    assert l.ink_layernorm_rows(None, 0, None, None, 1e-6, None, 1, 4, None, None, 4, 0, 0, None) == 1
+    assert l.ink_add_split_f16(16, None, 0, 16, 8, 3, None) == 1            # C % 4 != 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -62,3 +62,66 @@ def test_single_process_is_passthrough():
     out = idist.broadcast_state_dict({"x": ((3,), torch.float32)}, sd, "cpu")
     assert torch.equal(out["x"], sd["x"]) and idist.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
     assert idist.max_over_ranks(3.5, "cpu") == 3.5
+
+
+_RANK_SCRIPT = """
+import json, os, sys, torch
+sys.path.insert(0, %r)
+from inklayer_amd import dist as idist
+rank, world, local = idist.init_process_group("gloo")
+assert world == 2 and os.environ["MASTER_ADDR"] == "127.0.0.1"
+if len(sys.argv) > 1 and sys.argv[1] == "fail" and rank == 1:
+    sys.exit(7)
+t = idist.max_over_ranks(float(rank + 1), "cpu")
+idist.barrier()
+print("noise from rank", rank)
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "max": t, "shard": idist.shard_indices(6, rank, world)}))
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_launch_ranks_spawns_world2_and_returns_rank0_stdout():
+    """`bench.py --gpus N` without an external launcher goes through dist.launch_ranks: N fresh processes with the
+    torchrun environment on 127.0.0.1, rank 0's stdout (the JSON line) handed back, non-zero if any rank fails."""
+    import json
+    import sys
+    from pathlib import Path
+    from inklayer_amd import dist as idist
+    root = str(Path(__file__).resolve().parent.parent)
+    rc, out = idist.launch_ranks([sys.executable, "-c", _RANK_SCRIPT % root], 2, timeout_s=300)
+    assert rc == 0, out
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "rank 1" not in out
+    assert json.loads(lines[0]) == {"n_gpus": 2, "max": 2.0, "shard": [0, 2, 4]}
+    rc, _ = idist.launch_ranks([sys.executable, "-c", _RANK_SCRIPT % root, "fail"], 2, timeout_s=300)
+    assert rc == 7
+
+
+def test_bench_self_launch_path_is_taken_without_touching_the_gpu(monkeypatch):
+    """bench.main() with --gpus 2 and no WORLD_SIZE must delegate to launch_ranks (re-running this very script per
+    rank) BEFORE any torch.cuda call."""
+    import sys
+    import importlib
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    bench = importlib.import_module("bench")
+    from inklayer_amd import dist as idist
+    seen = {}
+
+    def fake_launch(cmd, world, timeout_s=None, extra_env=None):
+        seen["cmd"], seen["world"] = cmd, world
+        return 0, '{"n_gpus": 2}\n'
+
+    import torch
+    monkeypatch.setattr(idist, "launch_ranks", fake_launch)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: (_ for _ in ()).throw(AssertionError("GPU touched")))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    import pytest
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and seen["world"] == 2
+    assert seen["cmd"][0] == sys.executable and seen["cmd"][1].endswith("bench.py") and "--gpus" in seen["cmd"]

@@ -1,0 +1,71 @@
+"""FULL-DEPTH parity (BASELINE configs 2 and 3 at the sizes bench.py times): the 32-block SAM ViT-H at 1024x1024 and
+the 6+6-layer GroundingDINO at 800x800 on the HIP path against the CPU oracle, on one synthetic sketch.
+North-star tolerance: mask IoU >= 0.999 per instance.  GPU box only (the oracle runs ~1 min on the host cores)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BOXES = torch.tensor([[100.0, 80.0, 700.0, 600.0], [300.0, 300.0, 900.0, 760.0], [20.0, 500.0, 400.0, 1000.0],
+                      [600.0, 50.0, 1000.0, 400.0], [0.0, 0.0, 1023.0, 1023.0], [450.0, 450.0, 560.0, 600.0]])
+TAPS = (8, 16, 24, 32)
+
+
+def _l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def _iou(got, ref):
+    inter = (got & ref).flatten(1).sum(1).double()
+    union = (got | ref).flatten(1).sum(1).double()
+    return (inter / union.clamp(min=1)).tolist()
+
+
+def _run_both(dev, sd):
+    """(oracle logits [n,H,W], oracle stage taps, HIP masks, HIP logits, HIP stage taps) for one weight set."""
+    from PIL import Image
+    from oracle import sam_ref
+    from inklayer_amd import sam, synthetic
+    img = synthetic.synthetic_sketch(0)
+    oc = sam_ref.SamConfig()
+    taps = {k: None for k in TAPS}
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    ref_logits, _, _ = sam_ref.run_sam(sd, oc, img, BOXES, return_logits=True, taps=taps)
+    eng = sam.SamEngine(sd, sam.SamConfig(), dev, max_batch=1)
+    pred = sam.SamPredictor(eng)
+    rev = np.ascontiguousarray(img[..., ::-1])                 # run_SAM's channel quirk (InkLayer/segmentor/sam.py:24-26)
+    dimg = torch.from_numpy(rev).to(dev)
+    got_taps = {k: eng.encode([dimg], upto=k)[0].float().cpu().clone() for k in TAPS}
+    pred.set_image(rev)
+    got_taps[-1] = pred.features.float().cpu().clone()
+    logits, _, _ = pred.predict_torch(None, None, boxes=pred.apply_boxes(BOXES), return_logits=True)
+    masks = sam.run_SAM(Image.fromarray(img), BOXES, engine=eng)
+    del eng
+    torch.cuda.empty_cache()
+    return ref_logits[:, 0], taps, np.stack(masks), logits[:, 0].cpu(), got_taps
+
+
+@torch.no_grad()
+def test_full_depth_vith_random_weights_iou(dev):
+    """Weight set (i): seeded random weights (noise-like masks: the adversarial case for a threshold at 0)."""
+    from oracle import sam_ref
+    sd = sam_ref.seeded_state_dict(sam_ref.sam_param_shapes(sam_ref.SamConfig()), 11)
+    ref_logits, taps, masks, logits, got_taps = _run_both(dev, sd)
+    for k in TAPS:
+        e = _l2(got_taps[k], taps[k][0].reshape(4096, -1))
+        print(f"ViT-H after {k:2d} blocks: l2-rel {e:.2e}")
+        assert e < 3e-3
+    e = _l2(got_taps[-1], taps[-1][0].permute(1, 2, 0).reshape(4096, -1))
+    print(f"image embedding (after the neck): l2-rel {e:.2e}")
+    assert e < 3e-3
+    print(f"mask logits: l2-rel {_l2(logits, ref_logits):.2e}")
+    ref = ref_logits > 0
+    ious = _iou(torch.from_numpy(masks), ref)
+    print("full-depth mask IoU (random weights):", [round(i, 5) for i in ious],
+          "occupancy", [round(m.float().mean().item(), 3) for m in ref])
+    assert min(ious) >= 0.999, ious
+    flipped = torch.from_numpy(masks) != ref
+    tol = 1e-2 * ref_logits.std().item()
+    assert ref_logits[flipped].abs().max().item() < tol       # every flip lies within 1 % of the logit scale of 0

@@ -201,7 +201,9 @@ def test_detector_graph_replay_equals_eager(dev, small_dino):
     assert eng.graph_max_batch >= 1
     eager = [tuple(t.clone() for t in eng._forward_eager([im])) for im in imgs + [other]]
     eng._graphs.clear()
-    for im, (el, eb) in zip(imgs + [other] + imgs, eager + eager[:3]):      # capture, replays, second size, replays
+    eng._seen.clear()
+    # first sight of a size runs eager, the second captures, then replays; a second size gets its own graph
+    for im, (el, eb) in zip(imgs + [other, other] + imgs, eager + [eager[3]] + eager[:3]):
         gl, gb = eng.forward([im])
         assert torch.equal(gl, el) and torch.equal(gb, eb)
     assert len(eng._graphs) == 2
@@ -211,3 +213,27 @@ def test_detector_graph_replay_equals_eager(dev, small_dino):
         assert torch.equal(gl, eager[0][0])
     finally:
         eng.graph_max_batch = 1
+
+
+@torch.no_grad()
+def test_detector_caches_are_bounded(dev, small_dino):
+    """A run over sketches of many aspect ratios (one batch-1 forward per size, each size seen twice so that graphs ARE
+    captured) keeps at most graph_cache_size graphs / plan_cache_size plans and HBM plateaus instead of growing."""
+    sd, oc, eng, text = small_dino
+    rs = np.random.RandomState(4)
+    eng._graphs.clear(); eng._seen.clear(); eng._plans.clear()
+    sizes = [(160 + 32 * i, 224) for i in range(eng.graph_cache_size + 6)]
+    mem = []
+    for h, w in sizes:
+        im = torch.from_numpy(rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)).to(dev)
+        for _ in range(2):
+            eng.forward([im])
+        torch.cuda.synchronize()
+        mem.append(torch.cuda.memory_allocated(dev))
+    assert len(eng._graphs) == eng.graph_cache_size and len(eng._plans) <= eng.plan_cache_size
+    k = eng.graph_cache_size
+    growth_early = mem[k - 1] - mem[0]
+    growth_late = mem[-1] - mem[k + 1]
+    print("allocated MB per size:", [round(m / 2 ** 20, 1) for m in mem])
+    assert growth_late < 0.5 * max(growth_early, 1 << 20) + (64 << 20)      # sizes differ a little; no linear growth
+    eng._graphs.clear(); eng._seen.clear()

@@ -96,8 +96,8 @@ def test_decoder_matches_oracle(dev, small_vith):
     masks, low, iou, logits = eng.decode(emb.to(dev), boxes, input_hw, orig_hw, want_logits=True)
     mx, l2 = _rel(low, ref_low[:, 0])
     print(f"low-res logits: max-rel {mx:.2e} l2-rel {l2:.2e}")
-    assert mx < 1e-2 and l2 < 5e-3
-    assert _rel(iou, ref_iou)[0] < 1e-2
+    assert mx < 1e-4 and l2 < 2e-5                      # split-f16 decoder: fp32-grade
+    assert _rel(iou, ref_iou)[0] < 1e-4
     # postprocess kernel alone (same low-res input) must agree to f32 rounding
     from inklayer_amd import ops
     m2, lg2 = ops.sam_postprocess(ref_low[:, 0].contiguous().to(dev), 1024, input_hw, orig_hw, 0.0, True)
@@ -111,9 +111,11 @@ def test_decoder_matches_oracle(dev, small_vith):
     union = (got | ref_m).flatten(1).sum(1).double()
     print("decoder mask IoU:", (inter / union).tolist())
     # Random weights give noise-like masks (|logit| ~ 0 on a large share of the pixels), the worst
-    # case for a threshold at exactly 0: IoU >= 0.995 there, and EVERY flipped pixel must be explained by the
-    # stated fp tolerance, i.e. its fp32 reference logit lies within 1 % of the logit scale of the threshold.
-    assert (inter / union).min().item() > 0.995
+    # case for a threshold at exactly 0.  North-star tolerance: IoU >= 0.999 per instance; with the decoder on
+    # split-f16 operands the low-res logits agree to ~1e-6 and the masks are identical up to a handful of pixels.
+    # In addition EVERY flipped pixel must be explained by the stated fp tolerance, i.e. its fp32 reference logit lies
+    # within 1 % of the logit scale of the threshold.
+    assert (inter / union).min().item() >= 0.999
     flipped = got != ref_m
     tol = 1e-2 * ref_logits[:, 0].std().item()
     assert ref_logits[:, 0][flipped].abs().max().item() < tol
@@ -136,7 +138,7 @@ def test_run_sam_plugin_matches_oracle(dev, small_vith):
     assert len(got) == 3 and got[0].shape == (750, 750) and got[0].dtype == np.bool_
     ious = [float((g & r).sum() / max(1, (g | r).sum())) for g, r in zip(got, ref)]
     print("run_SAM IoU:", ious)
-    assert min(ious) > 0.995
+    assert min(ious) >= 0.999                                 # north-star tolerance
     tol = 1e-2 * ref_logits.std().item()                      # flips only where |fp32 logit| < 1 % of its scale
     for g, r, lg in zip(got, ref, ref_logits[:, 0].numpy()):
         assert np.abs(lg[g != r]).max(initial=0.0) < tol
@@ -158,15 +160,17 @@ def test_pipeline_two_stream_overlap_equals_serial(dev, small_vith):
     for ra, rb in zip(a, b):
         assert np.array_equal(ra.boxes_xyxy_norm, rb.boxes_xyxy_norm) and torch.equal(ra.masks, rb.masks)
         assert ra.masks.shape == (5, 600, 800) and ra.masks.dtype == torch.uint8
-    # pipelined batches (deferred stream join) give the same masks again
+    # host-to-host entry (pinned sketches in, pinned u8 masks out), three batches in flight over the two slots
     pp = pipeline.InkLayerPipeline(det, eng, overlap=True)
-    d_in, s_in, sz = pp.prepare(imgs)
-    outs = [pp.run_prepared(d_in, s_in, sz, top_n=5, defer_sync=True) for _ in range(3)]
-    pp.synchronize()
-    torch.cuda.synchronize()
-    for o in outs:
-        for ro, rb in zip(o, b):
-            assert torch.equal(ro.masks, rb.masks)
+    pinned = pp.pinned_like(imgs)
+    t1 = pp.submit_host(pinned, top_n=5)
+    t2 = pp.submit_host(pinned, top_n=5)
+    r1 = pp.collect_host(t1)
+    t3 = pp.submit_host(pinned, top_n=5)            # reuses slot 0 (collected above)
+    for got in (r1, pp.collect_host(t2), pp.collect_host(t3)):
+        for (xyxy, sc, pix, m), rb in zip(got, b):
+            assert m.dtype == np.uint8 and m.shape == (5, 600, 800)
+            assert np.array_equal(m, rb.masks.cpu().numpy()) and np.array_equal(xyxy, rb.boxes_xyxy_norm)
 
 
 @torch.no_grad()
