@@ -67,14 +67,20 @@ def run_inklayer_pipeline(input_path, out_base_dir, no_intermediate=False, inpai
         from InkLayer.refinement.refiner import run_refinement_on_sketch_dir
     except ImportError:
         print("InkLayer.refinement is not part of this build: skipping mask cleanup / NMS / refinement.")
+        refined = False
     else:
+        refined = True
         run_clean_masks_on_sketch_dir(out_dir)
         run_refinement_on_sketch_dir(out_dir, run_postprocess_boxes_on_sketch_dir(out_dir, sketch_iou_thresh=0.2))
     if inpaint:
         print("Inpainting (diffusers) is not part of this build: skipped.")
     else:
         print("Skipping inpainting step as 'inpaint' is set to False.")
-    if no_intermediate:
+    if no_intermediate and not refined:
+        # without the refinement stage none of the *_final artefacts exists: deleting the "intermediate" results
+        # would leave a directory with no results at all, so they are kept
+        print("no_intermediate: refinement was skipped, keeping the detector / segmentor outputs.")
+    elif no_intermediate:
         keep = {"masks_final", "complete_layers", "complete_layers_rgba", "bboxes_final.json",
                 "bboxes_final.png", "segmented_sketch_final.png", "depth_map.png", "input.png"}
         for item in os.listdir(out_dir):

@@ -44,7 +44,12 @@ def _compile(src: Path, force: bool, hdr_time: float) -> Path:
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
+def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> Path:
+    """ablation=True: a SEPARATE library (lib/libinklayer_hip_ablation.so, -DINK_ABLATION) that also contains the
+    measurement-only GEMM kernels (no-MFMA / no-epilogue / timeline variants); tools select it with
+    INKLAYER_HIP_LIB.  The product library never contains them."""
+    if ablation:
+        return _build_ablation(verbose)
     OBJDIR.mkdir(parents=True, exist_ok=True)
     srcs = sorted(CSRC.glob("*.hip"))
     if not srcs:
@@ -64,5 +69,25 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
+def _build_ablation(verbose: bool) -> Path:
+    odir = LIBDIR / "obj_ablation"
+    odir.mkdir(parents=True, exist_ok=True)
+    lib = LIBDIR / "libinklayer_hip_ablation.so"
+    objs = []
+    for src in sorted(CSRC.glob("*.hip")):
+        obj = odir / (src.stem + ".o")
+        r = subprocess.run([HIPCC, *FLAGS, "-DINK_ABLATION", "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+        objs.append(obj)
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[inklayer_amd.build] {lib} (ablation build)")
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, ablation="--ablation" in sys.argv)

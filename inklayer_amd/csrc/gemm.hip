@@ -575,6 +575,14 @@ extern "C" int ink_gemm_query_variant(int32_t M, int32_t N, int32_t K) {
 }
 extern "C" int ink_abi_version(void) { return INK_ABI_VERSION; }
 extern "C" int ink_gemm_set_variant(int32_t v) {
+  // A process-wide override for the sweep / debugging tools (not thread-safe, not used by the product path).
+  const int base = v >= 100 ? v % 100 : v;
+  bool ok = base == -1 || base == 0 || base == 10 || base == 11 || base == 12 || base == 14 || base == 16 ||
+            base == 32 || base == 40 || base == 42 || base == 45 || base == 47 || base == 53;
+#ifdef INK_ABLATION
+  ok = ok || (base >= 21 && base <= 23) || base == 43 || base == 44 || base == 46 || (base >= 48 && base <= 52);
+#endif
+  INK_CHECK_ARG(ok);
   g_variant = v;
   return INK_OK;
 }
@@ -592,8 +600,7 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
   INK_CHECK_ARG(((uintptr_t)p.C & 15) == 0);
   INK_CHECK_ARG(p.act >= 0 && p.act <= 2);
   hipStream_t s = (hipStream_t)stream;
-  static const int env_forced = getenv("INK_GEMM_VARIANT") ? atoi(getenv("INK_GEMM_VARIANT")) : -1;
-  int v = g_variant >= 0 ? g_variant : env_forced;
+  int v = g_variant;           // -1 (default): shape heuristic.  No environment variable reaches this function.
   int gm = 1;
   if (v >= 100) { gm = v / 100; v = v % 100; }
   if (p.K % 64 != 0) return launch_gemm<128, 128, 32, 2, 2, 2>(p, s);
@@ -602,8 +609,10 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     gm = 4;
   }
   // Production variants: 0 / 32 (128x128 tiles, K step 64 / 32), 10 (16-wave 256x256), 45 (ping-pong 256x320).
-  // The rest are the alternatives and the ablation / instrumentation builds DESIGN.md's measurements come from;
-  // they are only reachable through ink_gemm_set_variant / INK_GEMM_VARIANT (tools/gemm_sweep.py, gemm_stamps.py).
+  // 40/42/47/53/16/12/14/11 are alternative CORRECT tilings kept for tools/gemm_sweep.py (ink_gemm_set_variant).
+  // The ablation / instrumentation kernels DESIGN.md's measurements come from (they skip MFMAs, loads or the
+  // epilogue and return garbage) exist only in a library built with -DINK_ABLATION (`python -m inklayer_amd.build
+  // --ablation`, tools/gemm_stamps.py); the shipped library rejects their numbers in ink_gemm_set_variant.
   switch (v) {
     case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s, gm);       // 16 waves x (64x64), 2 x 64 KB stages
     case 45: return launch_gemm_pp<4, 5>(p, s, gm);                     // ping-pong 256x320, ring of 4 (144 KB)
@@ -615,6 +624,7 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     case 12: return launch_gemm<128, 256, 64, 2, 4, 2>(p, s);           // 8 waves x (64x64), 96 KB
     case 14: return launch_gemm<256, 128, 32, 4, 2, 2>(p, s, gm);       // 48 KB: 3 workgroups / CU
     case 11: return launch_gemm<256, 256, 32, 4, 4, 4>(p, s);           // 16 waves, counted-vmcnt ring of 4 x K32
+#ifdef INK_ABLATION
     case 21: return launch_gemm<256, 256, 64, 4, 4, 2, 1>(p, s, gm);    // variant 10 ablations: no DMA after tile 1
     case 22: return launch_gemm<256, 256, 64, 4, 4, 2, 2>(p, s, gm);    // ... no MFMA
     case 23: return launch_gemm<256, 256, 64, 4, 4, 2, 3>(p, s, gm);    // ... no epilogue
@@ -626,6 +636,7 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     case 50: return launch_gemm_pp<4, 5, 9>(p, s, gm);                  // ... without MFMA
     case 51: return launch_gemm_pp<4, 5, 11>(p, s, gm);                 // ... pure DMA stream
     case 52: return launch_gemm_pp<4, 5, 15>(p, s, gm);                 // ... pure DMA stream, all L2 hits
+#endif
     default: return launch_gemm<128, 128, 64, 2, 2, 2>(p, s);           // variant 0
   }
 }

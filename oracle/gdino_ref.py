@@ -539,6 +539,8 @@ def detector_forward(sd: SD, cfg: GDinoConfig, img: torch.Tensor, encoded_text: 
     coord_unsel = mlp(sd, t + "enc_out_bbox_embed.", om, 3) + props[None]
     # top-k by value, ties -> lower index first (torch.topk's tie order is unspecified)
     order = torch.sort(logits, dim=1, descending=True, stable=True)[1][:, :cfg.num_queries]
+    if stages is not None and "force_topk" in stages:     # test hook: pin the query selection (sensitivity probes)
+        order = stages["force_topk"].long()
     ref_unsig = torch.gather(coord_unsel, 1, order[..., None].expand(-1, -1, 4))
     tgt = sd[t + "tgt_embed.weight"][None].expand(B, -1, -1)
     if stages is not None:

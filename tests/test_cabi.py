@@ -46,6 +46,20 @@ def test_bad_arguments_are_rejected_without_launch():
     assert l.ink_add_split_f16(16, None, 0, 16, 8, 3, None) == 1            # C % 4 != 0
 
 
+def test_shipped_library_has_no_ablation_gemm_variants():
+    """VERDICT r1 / ADVICE: the no-MFMA / no-epilogue / timeline GEMM kernels return garbage fast and must not be
+    reachable in the product library (they live in the -DINK_ABLATION build used by tools/), and no environment
+    variable may select a GEMM variant."""
+    from inklayer_amd import _lib
+    l = _lib.lib()
+    for v in (21, 22, 23, 43, 44, 46, 48, 49, 50, 51, 52, 7, 99):
+        assert l.ink_gemm_set_variant(v) == 1, v
+    for v in (0, 10, 45, 445, -1):
+        assert l.ink_gemm_set_variant(v) == 0, v
+    src = (ROOT / "inklayer_amd" / "csrc" / "gemm.hip").read_text()
+    assert "getenv" not in src
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from inklayer_amd import _lib
     monkeypatch.setenv("INKLAYER_HIP_LIB", str(tmp_path / "nope.so"))

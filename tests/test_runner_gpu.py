@@ -1,0 +1,98 @@
+"""BASELINE config 1 on the HIP path (rows D0, D17, G, S0): the plugin entry points exactly as the reference's
+main.py drives them - InkLayer.runner.run_inklayer_pipeline -> InkLayer.detector.gdino.run_ft_dino_on_sketch ->
+InkLayer.utils.processing -> InkLayer.segmentor.sam.run_SAM - on a GENERATED sketch PNG, full-depth models (6+6 DINO
+layers, 32 ViT-H blocks) with seeded random weights (INKLAYER_RANDOM_WEIGHTS=1: no checkpoints exist offline),
+checked against the CPU oracle run on the same weights: output tree, bboxes.json, masks.  GPU box only."""
+import json
+import os
+import runpy
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@torch.no_grad()
+def test_runner_plugins_full_depth_against_oracle(dev, tmp_path, monkeypatch):
+    from PIL import Image
+    monkeypatch.setenv("INKLAYER_RANDOM_WEIGHTS", "1")
+    monkeypatch.syspath_prepend(str(ROOT))
+    import InkLayer.detector.gdino as DET
+    import InkLayer.segmentor.sam as SEG
+    import InkLayer.runner as R
+    from InkLayer.utils import processing as P
+    from inklayer_amd import gdino, sam, synthetic, weights_init
+    from oracle import gdino_ref, sam_ref
+
+    # a generated 750x750 RGBA sketch (the size/mode of the reference's data/bunny_cook_sketch.png)
+    W = H = 750
+    rgb = synthetic.synthetic_sketch(5, H, W)
+    png = tmp_path / "generated.sketch.png"
+    Image.fromarray(np.dstack([rgb, np.full((H, W), 255, np.uint8)]), "RGBA").save(png)
+
+    # ---- oracle detector on the weights the shim will generate (same seeds, same device generator)
+    gcfg = gdino.GDinoConfig()
+    gsd = {k: v.cpu() for k, v in weights_init.random_gdino_state_dict(gcfg, "cuda").items()}
+    text = weights_init.random_text_features(gcfg, "cuda").cpu()
+    sm, pid = gdino_ref.text_masks_and_position_ids(list(gdino.DEFAULT_TOKEN_IDS))
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    x = gdino_ref.load_image(np.asarray(Image.open(png).convert("RGB")))
+    ref_logits, ref_boxes = gdino_ref.detector_forward(gsd, gdino_ref.GDinoConfig(), x[None], text, sm, pid)
+    score = ref_logits[0].sigmoid().max(-1)[0]
+    srt = torch.sort(score, descending=True)[0]
+    gaps = srt[3:12] - srt[4:13]                 # keep 4..12 boxes: the widest score gap decides (random weights put
+    k = int(gaps.argmax()) + 4                   # hundreds of queries above the reference's 0.2)
+    thr = float((srt[k - 1] + srt[k]) / 2)
+    print(f"oracle: threshold {thr:.4f} keeps {k} boxes (gap {gaps.max().item():.4f})")
+    want_xyxy, want_sc = gdino_ref.postprocess_detections(ref_logits[0], ref_boxes[0], thr)
+
+    # ---- the product path, through the plugin surfaces
+    DET.model = None
+    SEG._engine = None
+    eng = DET.get_model()
+    eng.cfg.box_threshold = thr
+    try:
+        monkeypatch.setattr(sys, "argv", ["main.py", "--img", str(png), "--out_dir", str(tmp_path / "out")])
+        ref_main = Path("/root/reference/main.py")
+        if ref_main.exists():                    # build container only: the reference's own main.py, unchanged
+            runpy.run_path(str(ref_main), run_name="__main__")
+            out_dir = tmp_path / "out" / "generated"
+        else:                                    # GPU box: the call main.py makes (main.py:24)
+            out_dir = Path(R.run_inklayer_pipeline(str(png), str(tmp_path / "out")))
+        dino_out = DET.run_ft_dino_on_sketch(str(png))
+    finally:
+        eng.cfg.box_threshold = gcfg.box_threshold
+    assert out_dir == tmp_path / "out" / "generated"            # name = basename before the FIRST dot
+    assert sorted(p.name for p in out_dir.iterdir()) == ["bboxes.json", "bboxes.png", "input.png", "masks",
+                                                         "segmented_sketch.png"]
+    # D0 / D17: detector plugin output vs the oracle
+    got_xyxy = np.asarray(dino_out["bboxes"], dtype=np.float64)
+    assert got_xyxy.shape == (k, 4) and dino_out["labels"] == ["object"] * k
+    print("plugin boxes vs oracle: max", np.abs(got_xyxy - want_xyxy).max(), "scores max",
+          np.abs(np.asarray(dino_out["scores"]) - want_sc).max())
+    assert np.abs(got_xyxy - want_xyxy).max() < 1e-2 and np.abs(np.asarray(dino_out["scores"]) - want_sc).max() < 1e-2
+    # G: bboxes.json = int()-truncated pixel boxes re-normalised (runner.py:36-44): exact given the plugin's boxes
+    pil = Image.open(png).convert("RGB")
+    boxes_tensor, _ = P.process_dino_output(dino_out, pil)
+    saved = json.loads((out_dir / "bboxes.json").read_text())
+    assert saved["bboxes"] == [[int(v[0]) / W, int(v[1]) / H, int(v[2]) / W, int(v[3]) / H] for v in boxes_tensor.tolist()]
+    assert saved["scores"] == dino_out["scores"]
+    # S0: masks/mask_i.png (PIL mode "1") vs the full-depth SAM oracle prompted with the same boxes
+    ssd = {k_: v.cpu() for k_, v in weights_init.random_sam_state_dict(sam.SamConfig(), "cuda").items()}
+    ref_masks = sam_ref.run_sam(ssd, sam_ref.SamConfig(), np.asarray(pil), boxes_tensor)
+    ious = []
+    for i, r in enumerate(ref_masks):
+        m = Image.open(out_dir / "masks" / f"mask_{i}.png")
+        assert m.mode == "1" and m.size == (W, H)
+        g = np.asarray(m, dtype=bool)
+        ious.append(float((g & r).sum() / max(1, (g | r).sum())))
+    print("runner masks vs oracle IoU:", [round(v, 5) for v in ious])
+    assert len(ious) == k and min(ious) >= 0.999
+    DET.model = None
+    SEG._engine = None
+    torch.cuda.empty_cache()

@@ -4,6 +4,9 @@ import sys
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import os
+from inklayer_amd import build as _b
+os.environ.setdefault("INKLAYER_HIP_LIB", str(_b.build(ablation=True, verbose=False)))   # ablation kernels live in their own .so
 from inklayer_amd import ops, _lib
 
 dev = torch.device("cuda:0")
