@@ -79,9 +79,12 @@ class InkLayerPipeline:
         self.overlap = overlap
         self.s_det = torch.cuda.Stream(device=self.dev) if overlap else None
         self.s_seg = torch.cuda.Stream(device=self.dev) if overlap else None
-        # host <-> device traffic of the host-to-host entry points rides its own stream: the upload of batch i+1 and
-        # the mask download of batch i run under the compute of the neighbouring batch (two pinned slots)
-        self.s_copy = torch.cuda.Stream(device=self.dev)
+        # host <-> device traffic of the host-to-host entry points rides its own streams, one per direction (on ONE
+        # stream the upload of batch i+1 would queue behind the mask download of batch i and put both on the
+        # critical path): the upload of batch i+1 and the download of batch i run under the neighbouring batch's
+        # compute (two pinned slots)
+        self.s_h2d = torch.cuda.Stream(device=self.dev)
+        self.s_d2h = torch.cuda.Stream(device=self.dev)
         self._host_in: List[Optional[torch.Tensor]] = [None, None]
         self._host_out: List[Optional[torch.Tensor]] = [None, None]
         self._slot_free: List[Optional[torch.cuda.Event]] = [None, None]
@@ -118,10 +121,10 @@ class InkLayerPipeline:
         cur = torch.cuda.current_stream(self.dev)
         if self._slot_free[slot] is not None:
             self._slot_free[slot].synchronize()           # the download that last used this slot has finished
-        with torch.cuda.stream(self.s_copy):
+        with torch.cuda.stream(self.s_h2d):
             raw = [t.to(self.dev, non_blocking=True) for t in images_pinned]
             up = torch.cuda.Event()
-            up.record(self.s_copy)
+            up.record(self.s_h2d)
         cur.wait_event(up)
         for r in raw:
             r.record_stream(cur)
@@ -130,9 +133,9 @@ class InkLayerPipeline:
         if self._host_out[slot] is None or self._host_out[slot].numel() < total:
             self._host_out[slot] = torch.empty(max(total, 1), dtype=torch.uint8, pin_memory=True)
         hbuf = self._host_out[slot]
-        self.s_copy.wait_stream(cur)
+        self.s_d2h.wait_stream(cur)
         views, off = [], 0
-        with torch.cuda.stream(self.s_copy):
+        with torch.cuda.stream(self.s_d2h):
             # masks of consecutive images that share one postprocess launch are one contiguous device tensor:
             # copy run by run (usually ONE transfer per batch)
             i = 0
@@ -146,7 +149,7 @@ class InkLayerPipeline:
                     n_el += int(res[j].masks.numel())
                 if n_el > 0:
                     src = torch.as_strided(base, (n_el,), (1,))
-                    src.record_stream(self.s_copy)
+                    src.record_stream(self.s_d2h)
                     hbuf[off:off + n_el].copy_(src, non_blocking=True)
                 for k in range(i, j + 1):
                     m = res[k].masks
@@ -154,7 +157,7 @@ class InkLayerPipeline:
                     off += int(m.numel())
                 i = j + 1
             done = torch.cuda.Event()
-            done.record(self.s_copy)
+            done.record(self.s_d2h)
         self._slot_free[slot] = done
         return HostTicket(slot, done, [(r.boxes_xyxy_norm, r.scores, r.boxes_pixel) for r in res], views)
 
