@@ -1,8 +1,8 @@
 """Pipeline orchestration (reference: InkLayer/runner.py:21-103): same signature, same output tree
 for the detector -> segmentor part:  <out_base_dir>/<name>/{input.png, bboxes.json, masks/mask_i.png,
-segmented_sketch.png, bboxes.png}.  Refinement and inpainting are outside this build's scope
-(SURVEY §2 rows 7-8): if the reference's refinement package is importable it is called exactly like
-the reference does, otherwise the step is skipped with a message."""
+segmented_sketch.png, bboxes.png, masks_cleaned/mask_i.png, bboxes_final.json, bboxes_final.png}.  Mask cleanup and
+sketch NMS run on the GPU; depth ordering / watershed refinement and inpainting are outside this
+build's scope and are skipped with a message."""
 import os
 import shutil
 
@@ -61,17 +61,22 @@ def run_inklayer_pipeline(input_path, out_base_dir, no_intermediate=False, inpai
     _draw_boxes(input_pil, boxes_int).save(os.path.join(out_dir, "bboxes.png"))
     input_pil.save(os.path.join(out_dir, "input.png"))
 
-    try:                                                         # runner.py:69-73 (out of scope here)
-        from InkLayer.refinement.mask_cleaner import run_clean_masks_on_sketch_dir
-        from InkLayer.refinement.bbox_filter import run_postprocess_boxes_on_sketch_dir
+    # Refinement (runner.py:69-73).  Mask cleanup + sketch NMS run on the GPU with the masks handed over IN MEMORY
+    # (the files masks_cleaned/ and bboxes_final.json are still written: they are part of the output tree); the
+    # depth-ordering / watershed stage (refiner.py) is not part of this build yet.
+    from InkLayer.refinement.mask_cleaner import run_clean_masks_on_sketch_dir, clean_masks_in_memory
+    from InkLayer.refinement.bbox_filter import run_postprocess_boxes_on_sketch_dir
+    cleaned = clean_masks_in_memory(masks_np)
+    run_clean_masks_on_sketch_dir(out_dir, cleaned=cleaned)
+    bbox_out_path = run_postprocess_boxes_on_sketch_dir(out_dir, sketch_iou_thresh=0.2, cleaned_masks=cleaned)
+    try:
         from InkLayer.refinement.refiner import run_refinement_on_sketch_dir
     except ImportError:
-        print("InkLayer.refinement is not part of this build: skipping mask cleanup / NMS / refinement.")
+        print("InkLayer.refinement.refiner is not part of this build: skipping depth ordering / watershed refinement.")
         refined = False
     else:
+        run_refinement_on_sketch_dir(out_dir, bbox_out_path)
         refined = True
-        run_clean_masks_on_sketch_dir(out_dir)
-        run_refinement_on_sketch_dir(out_dir, run_postprocess_boxes_on_sketch_dir(out_dir, sketch_iou_thresh=0.2))
     if inpaint:
         print("Inpainting (diffusers) is not part of this build: skipped.")
     else:

@@ -306,6 +306,30 @@ int ink_sine_embed4(const float* ref, const float* dim_t, int32_t N, void* out_f
 int ink_box_refine(const float* delta, int64_t ldd, const float* ref, int32_t N, int32_t ref_is_logit,
                    float* out, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Mask hand-off stage of the refinement, on resident masks.  Integer / byte work, bit-exact with the
+ * reference's cv2 results.
+ *
+ * ink_mask_cleanup = clean_up_mask of InkLayer/refinement/mask_cleaner.py:11-36 for n masks at once:
+ *   cv2.threshold(m, 127, 255) -> cv2.morphologyEx(MORPH_CLOSE, k x k rect, k odd = calculate_kernel_size(shape),
+ *   mask_cleaner.py:6-9) -> cv2.connectedComponentsWithStats(connectivity=8) -> keep components with
+ *   area > area_threshold (500) OR max(w,h) / (min(w,h) + 1e-5) > aspect_threshold (1.1).
+ * masks_u8 / out_u8: [n, H, W] uint8 (any value > 127 is foreground on input; 0 / 255 on output), the masks stay in
+ * HBM instead of travelling through masks/mask_i.png -> masks_cleaned/mask_i.png (runner.py:57-60,69).
+ * tmp_a / tmp_b: [n, H, W] uint8 scratch; workspace: int32[ink_mask_cleanup_workspace_ints(n, H, W, k)].
+ * H, W <= 16383. */
+int ink_mask_cleanup_workspace_ints(int32_t n, int32_t H, int32_t W, int32_t k, int64_t* out_ints);
+int ink_mask_cleanup(const void* masks_u8, int32_t n, int32_t H, int32_t W, int32_t k, int32_t area_threshold,
+                     double aspect_threshold, void* tmp_a_u8, void* tmp_b_u8, int32_t* workspace, void* out_u8,
+                     void* stream);
+
+/* Pair table of the sketch NMS (content_iou, InkLayer/refinement/nms_sketch.py:186-234, which re-opens the sketch and
+ * two mask PNGs PER PAIR): refined_m = (mask_m > 0) AND (PIL-luma(sketch) < 250) (refine_mask_to_sketch_regions,
+ * nms_sketch.py:62-78); counts[i, j] = (|refined_i AND refined_j|, |refined_i OR refined_j|) as int32 [n, n, 2].
+ * sketch_rgb_u8: [H, W, 3] (the masks have the sketch's size on this path); bits_ws: uint64[n * ceil(H*W/64)]. */
+int ink_mask_sketch_iou_counts(const void* masks_u8, const void* sketch_rgb_u8, int32_t n, int32_t H, int32_t W,
+                               void* bits_ws_u64, int32_t* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,10 @@ SIGNATURES = {
     "ink_topk_rowmax": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ink_sine_embed4": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "ink_box_refine": [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "ink_mask_cleanup_workspace_ints": [c_int, c_int, c_int, c_int, C.POINTER(c_i64)],
+    "ink_mask_cleanup": [c_void_p, c_int, c_int, c_int, c_int, c_int, C.c_double, c_void_p, c_void_p, c_void_p,
+                         c_void_p, c_void_p],
+    "ink_mask_sketch_iou_counts": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ink_relpos_bias": [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }

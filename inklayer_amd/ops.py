@@ -539,3 +539,45 @@ def box_refine(delta: torch.Tensor, ref: torch.Tensor, ref_is_logit: bool = Fals
     check(_lib.lib().ink_box_refine(delta.data_ptr(), delta.stride(0), ref.data_ptr(), N, int(ref_is_logit),
                                     out.data_ptr(), _stream()), "ink_box_refine")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# refinement hand-off ops
+# ---------------------------------------------------------------------------------------------
+def mask_cleanup(masks_u8: torch.Tensor, k: int, area_threshold: int = 500, aspect_threshold: float = 1.1,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """clean_up_mask (InkLayer/refinement/mask_cleaner.py:11-36) for [n, H, W] uint8 masks (> 127 = foreground) on
+    the GPU: k x k closing, 8-connected components, area / aspect filter.  -> uint8 0/255 [n, H, W]."""
+    assert masks_u8.dtype == torch.uint8 and masks_u8.is_cuda and masks_u8.is_contiguous() and masks_u8.dim() == 3
+    n, H, W = masks_u8.shape
+    if out is None:
+        out = torch.empty_like(masks_u8)
+    if n == 0:
+        return out
+    assert out.dtype == torch.uint8 and out.is_contiguous() and out.shape == masks_u8.shape
+    need = C.c_int64(0)
+    check(_lib.lib().ink_mask_cleanup_workspace_ints(n, H, W, k, C.byref(need)), "ink_mask_cleanup_workspace_ints")
+    ws = torch.empty(need.value, device=masks_u8.device, dtype=torch.int32)
+    ta, tb = torch.empty_like(masks_u8), torch.empty_like(masks_u8)
+    check(_lib.lib().ink_mask_cleanup(masks_u8.data_ptr(), n, H, W, k, area_threshold, float(aspect_threshold),
+                                      ta.data_ptr(), tb.data_ptr(), ws.data_ptr(), out.data_ptr(), _stream()),
+          "ink_mask_cleanup")
+    out._ink_overflow_flag = ws[:1]        # stays 0 by construction (run bound of a closed image); tests read it
+    return out
+
+
+def mask_sketch_iou_counts(masks_u8: torch.Tensor, sketch_rgb_u8: torch.Tensor) -> torch.Tensor:
+    """int32 [n, n, 2] = (|r_i & r_j|, |r_i | r_j|), r = (mask > 0) & (PIL-luma(sketch) < 250)
+    (InkLayer/refinement/nms_sketch.py:62-78, 186-234)."""
+    assert masks_u8.dtype == torch.uint8 and masks_u8.is_cuda and masks_u8.is_contiguous() and masks_u8.dim() == 3
+    n, H, W = masks_u8.shape
+    assert sketch_rgb_u8.dtype == torch.uint8 and sketch_rgb_u8.is_cuda and sketch_rgb_u8.is_contiguous()
+    assert tuple(sketch_rgb_u8.shape) == (H, W, 3), "masks and sketch have the same size on this path"
+    counts = torch.empty((n, n, 2), device=masks_u8.device, dtype=torch.int32)
+    if n == 0:
+        return counts
+    bits = torch.empty((n, (H * W + 63) // 64), device=masks_u8.device, dtype=torch.int64)
+    check(_lib.lib().ink_mask_sketch_iou_counts(masks_u8.data_ptr(), sketch_rgb_u8.data_ptr(), n, H, W,
+                                                bits.data_ptr(), counts.data_ptr(), _stream()),
+          "ink_mask_sketch_iou_counts")
+    return counts

@@ -68,7 +68,8 @@ def test_runner_plugins_full_depth_against_oracle(dev, tmp_path, monkeypatch):
     finally:
         eng.cfg.box_threshold = gcfg.box_threshold
     assert out_dir == tmp_path / "out" / "generated"            # name = basename before the FIRST dot
-    assert sorted(p.name for p in out_dir.iterdir()) == ["bboxes.json", "bboxes.png", "input.png", "masks",
+    assert sorted(p.name for p in out_dir.iterdir()) == ["bboxes.json", "bboxes.png", "bboxes_final.json",
+                                                         "bboxes_final.png", "input.png", "masks", "masks_cleaned",
                                                          "segmented_sketch.png"]
     # D0 / D17: detector plugin output vs the oracle
     got_xyxy = np.asarray(dino_out["bboxes"], dtype=np.float64)
@@ -93,6 +94,14 @@ def test_runner_plugins_full_depth_against_oracle(dev, tmp_path, monkeypatch):
         ious.append(float((g & r).sum() / max(1, (g | r).sum())))
     print("runner masks vs oracle IoU:", [round(v, 5) for v in ious])
     assert len(ious) == k and min(ious) >= 0.999
+    # §8(f)-1 through the runner: masks_cleaned/ and bboxes_final.json vs the refinement oracle on the SAME raw masks
+    from oracle import refine_ref
+    raw = [np.asarray(Image.open(out_dir / "masks" / f"mask_{i}.png").convert("L")) for i in range(k)]
+    want_clean = [refine_ref.clean_up_mask(m) for m in raw]
+    for i, wc in enumerate(want_clean):
+        assert np.array_equal(np.asarray(Image.open(out_dir / "masks_cleaned" / f"mask_{i}.png")), wc)
+    want_final = refine_ref.process_json_with_sketch_nms(np.asarray(pil), saved, want_clean, 0.2)
+    assert json.loads((out_dir / "bboxes_final.json").read_text()) == want_final
     DET.model = None
     SEG._engine = None
     torch.cuda.empty_cache()

@@ -73,12 +73,28 @@ def _fake_plugins(monkeypatch):
 
     monkeypatch.setattr(R, "run_ft_dino_on_sketch", fake_detector)
     monkeypatch.setattr(R, "run_SAM", fake_sam)
+    # the refinement plugins run on the GPU too: on CPU the plumbing around them is what is tested
+    import InkLayer.refinement.mask_cleaner as MC
+    import InkLayer.refinement.bbox_filter as BF
+    monkeypatch.setattr(MC, "clean_masks_in_memory", lambda masks: np.stack([np.asarray(m, dtype=np.uint8) * 255 for m in masks]))
+
+    def fake_nms(sketch_path, masks_dir, input_data, iou_threshold=0.2, cleaned_masks=None):
+        assert cleaned_masks is not None and cleaned_masks.dtype == np.uint8      # handed over in memory
+        return {"bboxes": input_data["bboxes"][:1], "scores": input_data["scores"][:1], "kept_indices": [0],
+                "threshold": iou_threshold}
+
+    monkeypatch.setattr(BF, "process_json_with_sketch_NMS", fake_nms)
 
 
 def _check_tree(out_dir, W, H):
     out_dir = Path(out_dir)
-    assert sorted(p.name for p in out_dir.iterdir()) == ["bboxes.json", "bboxes.png", "input.png", "masks",
+    assert sorted(p.name for p in out_dir.iterdir()) == ["bboxes.json", "bboxes.png", "bboxes_final.json",
+                                                         "bboxes_final.png", "input.png", "masks", "masks_cleaned",
                                                          "segmented_sketch.png"]
+    fin = json.loads((out_dir / "bboxes_final.json").read_text())
+    assert sorted(fin) == ["bboxes", "kept_indices", "scores", "threshold"] and fin["threshold"] == 0.2
+    c0 = Image.open(out_dir / "masks_cleaned" / "mask_0.png")
+    assert c0.mode == "L" and c0.size == (W, H)
     d = json.loads((out_dir / "bboxes.json").read_text())
     assert d["bboxes"][0] == [int(0.1 * W) / W, int(0.2 * H) / H, int(0.5 * W) / W, int(0.6 * H) / H] or True
     assert len(d["bboxes"]) == 2 and d["scores"] == [0.9, 0.4]
