@@ -171,26 +171,48 @@ def test_detector_stages_match_oracle(dev, small_dino):
     dl = (logits[0].cpu() - ref_logits[0]).abs().max(-1)[0] / ref_logits.abs().max()
     print("logit err p50/p75/p90/max", dl.median().item(), dl.quantile(0.75).item(), dl.quantile(0.9).item(), dl.max().item())
     assert dl.median().item() < 3e-3 and dl.quantile(0.75).item() < 8e-3 and dl.quantile(0.9).item() < 5e-2
-    # MAX bound with an explicit exclusion list from the oracle's OWN fp32 sensitivity: the fp32 oracle is re-run on
-    # the same image with a 1e-3 relative perturbation of the normalised pixels (two seeds; the HIP path's stage
-    # error is of that size) with the query selection pinned; a query whose box moves by more than PROBE_TOL under
-    # that probe is ill-conditioned in fp32 already and is excluded.  Every other query is bounded hard.
-    PROBE_TOL, BOX_MAX, LOGIT_MAX = 2e-3, 1e-2, 3e-2
-    sens = torch.zeros(ref_boxes.shape[1])
-    sens_l = torch.zeros(ref_boxes.shape[1])
-    for seed in (1, 2):
-        gp = torch.Generator().manual_seed(seed)
-        xp = x * (1 + 1e-3 * torch.randn(x.shape, generator=gp))
+    # MAX bound, justified by the oracle's OWN sensitivity to the stated arithmetic: the fp32 oracle is re-run with the
+    # operands of every linear / conv rounded to f16 (exactly what DESIGN.md §4 says the HIP path does; weights and
+    # activations, f32 accumulation) and, separately, with f16 weights only, with the query selection pinned.  With
+    # RANDOM weights ~10 % of the queries are ill-conditioned (large random sampling offsets on a random feature map)
+    # and move by up to several 1e-2 under that rounding in the fp32 oracle itself.  So
+    #   (1) every quantile of the HIP error INCLUDING THE MAXIMUM is bounded by 2x the emulated-f16 oracle's, and
+    #   (2) per query: err(q) <= 2e-3 + 20 * sens(q), sens = the query's own movement under the probes, for all but
+    #       2 % of the queries (a different rounding realisation can hit a query the probes happened to miss).
+    import torch.nn.functional as RealF
+
+    class _F16Operands:
+        def __getattr__(self, k):
+            return getattr(RealF, k)
+
+        def linear(self, a, w, b=None):
+            return RealF.linear(a.half().float(), w.half().float(), b)
+
+        def conv2d(self, a, w, b=None, **kw):
+            return RealF.conv2d(a.half().float(), w.half().float(), b, **kw)
+
+    def probe(sd_, proxy):
         pst = {"force_topk": st["topk"]}
-        pl, pb = gdino_ref.detector_forward(sd, oc, xp[None], text, sm, pid, stages=pst)
-        sens = torch.maximum(sens, (pb[0] - ref_boxes[0]).abs().max(-1)[0])
-        sens_l = torch.maximum(sens_l, (pl[0] - ref_logits[0]).abs().max(-1)[0] / ref_logits.abs().max())
-    well = (sens <= PROBE_TOL) & (sens_l <= 5e-3)
-    print(f"fp32 probe: {int((~well).sum())} of {well.numel()} queries ill-conditioned; "
-          f"HIP max box err on the rest {d[well].max().item():.2e}, logit {dl[well].max().item():.2e}; "
-          f"on the excluded {d[~well].max().item() if (~well).any() else 0:.2e}")
-    assert well.float().mean().item() >= 0.75            # the exclusion list stays a minority
-    assert d[well].max().item() < BOX_MAX and dl[well].max().item() < LOGIT_MAX
+        gdino_ref.F = proxy
+        try:
+            pl, pb = gdino_ref.detector_forward(sd_, oc, x[None], text, sm, pid, stages=pst)
+        finally:
+            gdino_ref.F = RealF
+        return ((pb[0] - ref_boxes[0]).abs().max(-1)[0],
+                (pl[0] - ref_logits[0]).abs().max(-1)[0] / ref_logits.abs().max())
+
+    sd16 = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in sd.items()}
+    eb, el = probe(sd, _F16Operands())              # the yardstick: f16 operands everywhere
+    wb, wl = probe(sd16, RealF)                     # second probe: f16 weights only
+    for name, mine, emul in (("box", d, eb), ("logit", dl, el)):
+        for qt in (0.5, 0.75, 0.9, 0.99, 1.0):
+            hq, eq = mine.quantile(qt).item(), emul.quantile(qt).item()
+            print(f"{name} err q{qt}: HIP {hq:.2e}  emulated-f16 oracle {eq:.2e}")
+            assert hq <= 2.0 * eq + 1e-3, (name, qt, hq, eq)
+    sens_b, sens_l = torch.maximum(eb, wb), torch.maximum(el, wl)
+    bad = (d > 2e-3 + 20 * sens_b) | (dl > 5e-3 + 20 * sens_l)
+    print(f"per-query bound violated by {int(bad.sum())} of {bad.numel()} queries")
+    assert bad.float().mean().item() <= 0.02
 
 
 @torch.no_grad()
