@@ -330,6 +330,30 @@ int ink_mask_cleanup(const void* masks_u8, int32_t n, int32_t H, int32_t W, int3
 int ink_mask_sketch_iou_counts(const void* masks_u8, const void* sketch_rgb_u8, int32_t n, int32_t H, int32_t W,
                                void* bits_ws_u64, int32_t* counts, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Depth-Anything-V2 ViT-B pixel-side ops (the dense layers reuse ink_gemm_f16 / ink_flash_attn /
+ * ink_layernorm_rows).
+ *
+ * ink_depth_patchify = DepthAnythingV2.image2tensor (DA/dpt.py:199-221: BGR->RGB, /255, cv2.resize INTER_CUBIC to
+ * (nw, nh), (x - mean) / std) fused with the 14x14 / s14 patch gather of DA/dinov2_layers/patch_embed.py:
+ * image_u8 [H, W, 3] -> split-f16 im2col rows [ (nh/P)*(nw/P), 3*KP ], KP = 3*P*P rounded up to a multiple of 32
+ * (zero columns), column = c*P*P + ky*P + kx.  chan_reverse != 0 reads channel 2-c (cv2.imread's BGR order).
+ * mean3 / std3 are HOST pointers.  float64 arithmetic like cv2 on a CV_64F image. */
+int ink_depth_patchify(const void* image_u8, int32_t H, int32_t W, int32_t nh, int32_t nw, int32_t P, int32_t KP,
+                       const double* mean3, const double* std3, int32_t chan_reverse, void* out_f16, void* stream);
+
+/* F.interpolate(mode="bilinear", align_corners=True) on an NHWC f32 map [B, h, w, C] -> [B, H, W, C] (f32 and/or
+ * f16 copy): the up-samplings of FeatureFusionBlock (DA/util/blocks.py:136-146), of DPTHead.forward
+ * (DA/dpt.py:146) and of infer_image (DA/dpt.py:195).  C % 4 == 0 or C < 4. */
+int ink_resize_bilinear_ac_nhwc(const float* in, int32_t B, int32_t h, int32_t w, int32_t C, int32_t H, int32_t W,
+                                float* out_f32, void* out_f16, void* stream);
+
+/* 3x3 / pad 1 im2col of an NHWC f16 map with stride 1 or 2 and an optional ReLU applied to the gathered values
+ * (ResidualConvUnit's activation(x) before conv1, DA/util/blocks.py:69-70; the stride-2 resize conv of
+ * DA/dpt.py:72-77): [B*H*W, C] -> [B*OH*OW, 9*C], OH = (H - 1) / stride + 1. */
+int ink_im2col3x3_ex_f16(const void* in_f16, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t relu,
+                         void* out_f16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,10 @@ SIGNATURES = {
     "ink_mask_cleanup": [c_void_p, c_int, c_int, c_int, c_int, c_int, C.c_double, c_void_p, c_void_p, c_void_p,
                          c_void_p, c_void_p],
     "ink_mask_sketch_iou_counts": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "ink_depth_patchify": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                           c_int, c_void_p, c_void_p],
+    "ink_resize_bilinear_ac_nhwc": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "ink_im2col3x3_ex_f16": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "ink_relpos_bias": [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }

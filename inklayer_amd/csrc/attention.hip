@@ -636,6 +636,8 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
     INK_FA_X(80, 2, 7, true);
   } else if (p.head_dim == 80 && p.bias_mode == 0) {
     INK_FA(80, 0, 4);
+  } else if (p.head_dim == 64 && p.bias_mode == 0) {
+    INK_FA(64, 0, 4);
   } else if (p.head_dim == 32 && p.bias_mode == 0) {
     if (p.n_q <= 32) { INK_FA(32, 0, 1) } else { INK_FA(32, 0, 4) }
   } else if (p.head_dim == 32 && p.bias_mode == 3) {

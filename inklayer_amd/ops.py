@@ -581,3 +581,41 @@ def mask_sketch_iou_counts(masks_u8: torch.Tensor, sketch_rgb_u8: torch.Tensor) 
                                                 bits.data_ptr(), counts.data_ptr(), _stream()),
           "ink_mask_sketch_iou_counts")
     return counts
+
+
+# ---------------------------------------------------------------------------------------------
+# Depth-Anything-V2 pixel-side ops
+# ---------------------------------------------------------------------------------------------
+def depth_patchify(image_u8: torch.Tensor, nh: int, nw: int, P: int, KP: int, mean: Sequence[float],
+                   std: Sequence[float], chan_reverse: bool) -> torch.Tensor:
+    """image2tensor (cv2 cubic resize to (nh, nw), normalise) + 14x14 patch gather -> split-f16 [T, 3*KP]."""
+    assert image_u8.dtype == torch.uint8 and image_u8.is_cuda and image_u8.is_contiguous() and image_u8.shape[2] == 3
+    H, W = int(image_u8.shape[0]), int(image_u8.shape[1])
+    out = torch.empty(((nh // P) * (nw // P), 3 * KP), device=image_u8.device, dtype=F16)
+    check(_lib.lib().ink_depth_patchify(image_u8.data_ptr(), H, W, nh, nw, P, KP, (C.c_double * 3)(*mean),
+                                        (C.c_double * 3)(*std), int(chan_reverse), out.data_ptr(), _stream()),
+          "ink_depth_patchify")
+    return out
+
+
+def resize_bilinear_ac(x: torch.Tensor, B: int, h: int, w: int, H: int, W: int, out_dtype=F32) -> torch.Tensor:
+    """F.interpolate(bilinear, align_corners=True) of an NHWC f32 map [B*h*w, C] -> [B*H*W, C] (f32 or f16)."""
+    assert x.dtype == F32 and x.is_contiguous() and x.shape[0] == B * h * w
+    Cn = x.shape[1]
+    out = torch.empty((B * H * W, Cn), device=x.device, dtype=out_dtype)
+    check(_lib.lib().ink_resize_bilinear_ac_nhwc(x.data_ptr(), B, h, w, Cn, H, W,
+                                                 out.data_ptr() if out_dtype == F32 else None,
+                                                 out.data_ptr() if out_dtype == F16 else None, _stream()),
+          "ink_resize_bilinear_ac_nhwc")
+    return out
+
+
+def im2col3x3_ex(x: torch.Tensor, B: int, H: int, W: int, stride: int = 1, relu: bool = False) -> torch.Tensor:
+    """f16 NHWC [B*H*W, C] -> [B*OH*OW, 9*C] (pad 1, stride 1 or 2, optional ReLU on the gathered values)."""
+    assert x.dtype == F16 and x.is_contiguous() and x.shape[0] == B * H * W
+    Cn = x.shape[1]
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((B * OH * OW, 9 * Cn), device=x.device, dtype=F16)
+    check(_lib.lib().ink_im2col3x3_ex_f16(x.data_ptr(), B, H, W, Cn, stride, int(relu), out.data_ptr(), _stream()),
+          "ink_im2col3x3_ex_f16")
+    return out

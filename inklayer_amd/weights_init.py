@@ -189,3 +189,46 @@ def random_text_features(cfg, device, n_tokens: int = 4, seed: int = 2) -> torch
     """Stand-in for feat_map(BERT("object.")) [n_tokens, 256] (no bert-base-uncased offline)."""
     g = torch.Generator(device=device).manual_seed(seed)
     return 0.5 * torch.randn((n_tokens, cfg.hidden_dim), generator=g, device=device)
+
+
+def depth_param_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
+    """Parameter names/shapes of DepthAnythingV2("vitb") (DA/dpt.py:153-176, DA/dinov2.py:397-415)."""
+    D, P, Fe = cfg.embed_dim, cfg.patch_size, cfg.features
+    g = cfg.img_size // P
+    s: Dict[str, Tuple[int, ...]] = {
+        "pretrained.cls_token": (1, 1, D), "pretrained.pos_embed": (1, g * g + 1, D), "pretrained.mask_token": (1, D),
+        "pretrained.patch_embed.proj.weight": (D, 3, P, P), "pretrained.patch_embed.proj.bias": (D,),
+        "pretrained.norm.weight": (D,), "pretrained.norm.bias": (D,),
+    }
+    for i in range(cfg.depth):
+        p = f"pretrained.blocks.{i}."
+        s.update({p + "norm1.weight": (D,), p + "norm1.bias": (D,), p + "attn.qkv.weight": (3 * D, D),
+                  p + "attn.qkv.bias": (3 * D,), p + "attn.proj.weight": (D, D), p + "attn.proj.bias": (D,),
+                  p + "ls1.gamma": (D,), p + "norm2.weight": (D,), p + "norm2.bias": (D,),
+                  p + "mlp.fc1.weight": (cfg.mlp_ratio * D, D), p + "mlp.fc1.bias": (cfg.mlp_ratio * D,),
+                  p + "mlp.fc2.weight": (D, cfg.mlp_ratio * D), p + "mlp.fc2.bias": (D,), p + "ls2.gamma": (D,)})
+    oc, h = cfg.out_channels, "depth_head."
+    for i, c in enumerate(oc):
+        s[f"{h}projects.{i}.weight"], s[f"{h}projects.{i}.bias"] = (c, D, 1, 1), (c,)
+        s[f"{h}scratch.layer{i + 1}_rn.weight"] = (Fe, c, 3, 3)
+    s[h + "resize_layers.0.weight"], s[h + "resize_layers.0.bias"] = (oc[0], oc[0], 4, 4), (oc[0],)
+    s[h + "resize_layers.1.weight"], s[h + "resize_layers.1.bias"] = (oc[1], oc[1], 2, 2), (oc[1],)
+    s[h + "resize_layers.3.weight"], s[h + "resize_layers.3.bias"] = (oc[3], oc[3], 3, 3), (oc[3],)
+    for r in (1, 2, 3, 4):
+        p = f"{h}scratch.refinenet{r}."
+        s[p + "out_conv.weight"], s[p + "out_conv.bias"] = (Fe, Fe, 1, 1), (Fe,)
+        for u in (1, 2):
+            for c in (1, 2):
+                s[f"{p}resConfUnit{u}.conv{c}.weight"], s[f"{p}resConfUnit{u}.conv{c}.bias"] = (Fe, Fe, 3, 3), (Fe,)
+    s[h + "scratch.output_conv1.weight"], s[h + "scratch.output_conv1.bias"] = (Fe // 2, Fe, 3, 3), (Fe // 2,)
+    s[h + "scratch.output_conv2.0.weight"], s[h + "scratch.output_conv2.0.bias"] = (32, Fe // 2, 3, 3), (32,)
+    s[h + "scratch.output_conv2.2.weight"], s[h + "scratch.output_conv2.2.bias"] = (1, 32, 1, 1), (1,)
+    return s
+
+
+def random_depth_state_dict(cfg, device, seed: int = 3) -> Dict[str, torch.Tensor]:
+    sd = _fill(depth_param_shapes(cfg), device, seed)
+    for k in sd:
+        if k.endswith("gamma"):
+            sd[k] = 0.5 + 0.2 * sd[k]          # LayerScale
+    return sd

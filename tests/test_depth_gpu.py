@@ -1,0 +1,96 @@
+"""Depth-Anything-V2 ViT-B on the HIP path against oracle/depth_ref.py (pinned to the reference's own
+modules by tests/golden/depth_small.npz) on the same seeded weights.  GPU box only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max()).item(), ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture(scope="module")
+def depth_pair(dev):
+    from oracle import depth_ref
+    from inklayer_amd import depth
+    cfg = depth_ref.DepthConfig()
+    sd = depth_ref.seeded_state_dict(cfg, 31)
+    return sd, cfg, depth.DepthEngine(sd, depth.DepthConfig(), dev)
+
+
+def test_pixel_ops_match_torch(dev):
+    from inklayer_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2 * 19 * 23, 64, generator=g)
+    for (H, W) in ((37, 37), (38, 46), (74, 91), (19, 23)):
+        ref = torch.nn.functional.interpolate(x.view(2, 19, 23, 64).permute(0, 3, 1, 2), (H, W), mode="bilinear",
+                                              align_corners=True).permute(0, 2, 3, 1).reshape(-1, 64)
+        got = ops.resize_bilinear_ac(x.to(dev), 2, 19, 23, H, W)
+        assert (got.cpu() - ref).abs().max().item() < 2e-6
+        got16 = ops.resize_bilinear_ac(x.to(dev), 2, 19, 23, H, W, out_dtype=torch.float16)
+        assert (got16.cpu().float() - ref).abs().max().item() < 4e-3
+    one = torch.randn(30 * 40, 1, generator=g)
+    ref = torch.nn.functional.interpolate(one.view(1, 1, 30, 40), (75, 100), mode="bilinear", align_corners=True).reshape(-1, 1)
+    assert (ops.resize_bilinear_ac(one.to(dev), 1, 30, 40, 75, 100).cpu() - ref).abs().max().item() < 2e-6
+    # im2col: stride 1 / 2, ReLU on the way
+    m = torch.randn(2 * 9 * 11, 16, generator=g).half()
+    for stride, relu in ((1, False), (1, True), (2, False)):
+        src = m.float().view(2, 9, 11, 16).permute(0, 3, 1, 2)
+        if relu:
+            src = src.relu()
+        u = torch.nn.functional.unfold(src, 3, padding=1, stride=stride)            # [B, C*9, L] with (c, ky, kx) order
+        L = u.shape[-1]
+        ref = u.view(2, 16, 9, L).permute(0, 3, 2, 1).reshape(2 * L, 9 * 16)         # -> [(b, pix), (tap, c)]
+        got = ops.im2col3x3_ex(m.to(dev), 2, 9, 11, stride=stride, relu=relu)
+        assert torch.equal(got.cpu().float(), ref)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("hw", [(750, 750), (600, 800), (518, 518)])
+def test_depth_pipeline_matches_oracle(dev, depth_pair, hw):
+    """infer_image end to end: cubic resize (incl. the identity size), patch embedding, 12 ViT-B blocks with LayerScale,
+    DPT head, final align_corners resize.  Square 750^2 -> 518^2 (InkLayer's sketches) and 600x800 -> 518x686 (the
+    position-embedding interpolation path)."""
+    from oracle import depth_ref
+    from inklayer_amd import ops, synthetic
+    sd, cfg, eng = depth_pair
+    bgr = np.ascontiguousarray(synthetic.synthetic_sketch(4, hw[0], hw[1])[..., ::-1])
+    # image2tensor alone: the split-f16 patch rows reconstruct the oracle's normalised tensor
+    x_ref, _ = depth_ref.image2tensor(bgr, cfg)
+    nh, nw = x_ref.shape[-2:]
+    assert (nh, nw) == depth_ref.resize_shape(hw[0], hw[1])
+    pt = ops.depth_patchify(torch.from_numpy(bgr).to(dev), nh, nw, 14, eng.KP, cfg_mean(), cfg_std(), chan_reverse=True)
+    rec = (pt[:, :588].double() + pt[:, eng.KP:eng.KP + 588].double() / 64).cpu()
+    want = x_ref[0].unfold(1, 14, 14).unfold(2, 14, 14).permute(1, 2, 0, 3, 4).reshape(-1, 588).double()
+    assert (rec - want).abs().max().item() < 2e-6
+    assert pt[:, 588:eng.KP].abs().max().item() == 0
+    # whole network
+    st_ref, st = {}, {}
+    ref_net = depth_ref.forward(sd, cfg, x_ref, stages=st_ref)[0]
+    ref = depth_ref.infer_image(sd, cfg, bgr)
+    got = eng.infer_image(bgr, stages=st)
+    for i in range(4):
+        mx, l2 = _rel(st["feats"][i].float(), st_ref["feats"][i][0][0])
+        print(f"{hw}: ViT-B tap {i}: max-rel {mx:.2e} l2-rel {l2:.2e}")
+        assert l2 < 3e-3
+    for i in range(4):
+        rp = st_ref["path"][i][0].permute(1, 2, 0).reshape(-1, 128)
+        mx, l2 = _rel(st["path"][i], rp)
+        print(f"{hw}: refinenet path_{i + 1}: max-rel {mx:.2e} l2-rel {l2:.2e}")
+        assert l2 < 5e-3
+    mx, l2 = _rel(st["depth_net"], ref_net)
+    print(f"{hw}: network depth: max-rel {mx:.2e} l2-rel {l2:.2e}; depth max {ref_net.max().item():.3f}")
+    assert mx < 1e-2 and l2 < 5e-3
+    mx, l2 = _rel(got, torch.from_numpy(ref))
+    assert tuple(got.shape) == hw and mx < 1e-2 and l2 < 5e-3
+
+
+def cfg_mean():
+    return (0.485, 0.456, 0.406)
+
+
+def cfg_std():
+    return (0.229, 0.224, 0.225)

@@ -248,8 +248,9 @@ def test_detect_threshold_path_matches_oracle_postprocess(dev, small_dino):
     lg, bx = eng.forward([dimg])
     my_score = lg[0].cpu().sigmoid().max(-1)[0]
     keep_hip = my_score > thr
-    # detect() == threshold applied to forward()'s own outputs (the D17 code path itself), bit for bit
-    assert torch.equal(boxes, bx[0].cpu()[keep_hip]) and torch.equal(scores, my_score[keep_hip])
+    # detect() == threshold applied to forward()'s own outputs (the D17 code path itself); the scores to 1 ulp (torch's
+    # CPU sigmoid takes a vectorised or a scalar path depending on the tensor's strides)
+    assert torch.equal(boxes, bx[0].cpu()[keep_hip]) and torch.allclose(scores, my_score[keep_hip], atol=1e-6, rtol=0)
     agree = (keep_hip == keep_ref).float().mean().item()
     decisive = (score - thr).abs() > 0.05
     print(f"threshold {thr:.4f}: oracle keeps {int(keep_ref.sum())}, HIP keeps {int(keep_hip.sum())}, agreement {agree:.3f}, "
