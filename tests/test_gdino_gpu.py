@@ -236,16 +236,21 @@ def test_detect_threshold_path_matches_oracle_postprocess(dev, small_dino):
     mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
     x = ((torch.from_numpy(img).permute(2, 0, 1).float() / 255.0) - mean.view(3, 1, 1)) / std.view(3, 1, 1)
     sm, pid = gdino_ref.text_masks_and_position_ids(list(gdino.DEFAULT_TOKEN_IDS))
-    ref_logits, ref_boxes = gdino_ref.detector_forward(sd, oc, x[None], text, sm, pid)
+    dimg = torch.from_numpy(img).to(dev)
+    # The two-stage selection RANKS 22k encoder tokens by logits that differ by ~1e-3 relative between f16 and fp32:
+    # the selected SET agrees (>= 97 %, test_detector_stages_match_oracle) but its ORDER - which pairs each token with
+    # a learned tgt_embed row - does not (64 % of the positions here), and torch.topk's own order is just as arbitrary.
+    # Per-query comparisons therefore pin the oracle to the selection the HIP path made.
+    st = {}
+    lg, bx = eng._forward_eager([dimg], stages=st)
+    ref_logits, ref_boxes = gdino_ref.detector_forward(sd, oc, x[None], text, sm, pid, stages={"force_topk": st["topk"].cpu()})
     score = ref_logits[0].sigmoid().max(-1)[0]
     thr = float(score.median())
     assert 0.3 < thr < 0.95 and (score > thr).sum() > 100 and (score <= thr).sum() > 100
     want_xyxy, want_sc = gdino_ref.postprocess_detections(ref_logits[0], ref_boxes[0], thr)
     keep_ref = score > thr
-    dimg = torch.from_numpy(img).to(dev)
     eng.cfg.box_threshold = thr
     boxes, scores = eng.detect([dimg])[0]
-    lg, bx = eng.forward([dimg])
     my_score = lg[0].cpu().sigmoid().max(-1)[0]
     keep_hip = my_score > thr
     # detect() == threshold applied to forward()'s own outputs (the D17 code path itself); the scores to 1 ulp (torch's

