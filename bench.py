@@ -195,8 +195,8 @@ def main():
         # started without a launcher: become the launcher.  Nothing in this process has touched the GPU yet (importing
         # torch does not); the N ranks are fresh child processes running this same script.
         rc, out0 = idist.launch_ranks([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], args.gpus)
-        sys.stdout.write(out0)
-        sys.stdout.flush()
+        for line in out0.splitlines():       # rank 0's JSON line goes to stdout, any library chatter to stderr
+            print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
         sys.exit(rc)
 
     from inklayer_amd import ops, pipeline, synthetic
