@@ -2,7 +2,7 @@
 
 `get_depth_map(sketch_path) -> HxW float32 numpy` = DepthAnythingV2("vitb").infer_image(cv2.imread(sketch_path)).
 The model is a lazily created singleton kept resident in HBM (the reference builds it at import).  The mask-ordering
-logic of the reference's module (sort_sketch_masks and helpers, depth_sort.py:49-270) is not part of this build yet."""
+logic (sort_sketch_masks and helpers, depth_sort.py:49-295) is host code, as in the reference: inklayer_amd/refine_host.py."""
 import os
 
 import numpy as np
@@ -35,3 +35,13 @@ def get_depth_map(sketch_path):
     rgb = np.asarray(Image.open(sketch_path).convert("RGB"))
     bgr = np.ascontiguousarray(rgb[..., ::-1])                        # cv2.imread returns BGR
     return _get_engine().infer_image(bgr).cpu().numpy()
+
+
+def sort_sketch_masks(masks, bboxes, sketch_path, depth_sketch=None):
+    """depth_sort.py:244-295: -> (order deepest first, depth scores, containment graph)."""
+    from inklayer_amd import refine_host
+    assert os.path.exists(sketch_path), f"Sketch path {sketch_path} does not exist."
+    if depth_sketch is None:
+        depth_sketch = get_depth_map(sketch_path)
+    rgb = np.asarray(Image.open(sketch_path).convert("RGB"))
+    return refine_host.sort_sketch_masks([np.asarray(m) > 0 for m in masks], bboxes, rgb, depth_sketch)

@@ -1,8 +1,8 @@
 """Pipeline orchestration (reference: InkLayer/runner.py:21-103): same signature, same output tree
 for the detector -> segmentor part:  <out_base_dir>/<name>/{input.png, bboxes.json, masks/mask_i.png,
-segmented_sketch.png, bboxes.png, masks_cleaned/mask_i.png, bboxes_final.json, bboxes_final.png}.  Mask cleanup and
-sketch NMS run on the GPU; depth ordering / watershed refinement and inpainting are outside this
-build's scope and are skipped with a message."""
+segmented_sketch.png, bboxes.png, masks_cleaned/, bboxes_final.json, bboxes_final.png, masks_disjoint/, masks_final/,
+depth_map.png, segmented_sketch_final.png}.  Detector, segmentor, mask cleanup, sketch-NMS pair table and the depth model
+run on the GPU; inpainting (diffusers) is outside this build's scope and is skipped with a message."""
 import os
 import shutil
 
@@ -63,29 +63,20 @@ def run_inklayer_pipeline(input_path, out_base_dir, no_intermediate=False, inpai
 
     # Refinement (runner.py:69-73).  Mask cleanup + sketch NMS run on the GPU with the masks handed over IN MEMORY
     # (the files masks_cleaned/ and bboxes_final.json are still written: they are part of the output tree); the
-    # depth-ordering / watershed stage (refiner.py) is not part of this build yet.
+    # depth map comes from the GPU Depth-Anything-V2 engine; the depth ordering / mask growth / box assignment are
+    # sequential algorithms and run on the host as in the reference (inklayer_amd/refine_host.py).
     from InkLayer.refinement.mask_cleaner import run_clean_masks_on_sketch_dir, clean_masks_in_memory
     from InkLayer.refinement.bbox_filter import run_postprocess_boxes_on_sketch_dir
     cleaned = clean_masks_in_memory(masks_np)
     run_clean_masks_on_sketch_dir(out_dir, cleaned=cleaned)
     bbox_out_path = run_postprocess_boxes_on_sketch_dir(out_dir, sketch_iou_thresh=0.2, cleaned_masks=cleaned)
-    try:
-        from InkLayer.refinement.refiner import run_refinement_on_sketch_dir
-    except ImportError:
-        print("InkLayer.refinement.refiner is not part of this build: skipping depth ordering / watershed refinement.")
-        refined = False
-    else:
-        run_refinement_on_sketch_dir(out_dir, bbox_out_path)
-        refined = True
+    from InkLayer.refinement.refiner import run_refinement_on_sketch_dir
+    run_refinement_on_sketch_dir(out_dir, bbox_out_path, cleaned_masks=cleaned)
     if inpaint:
         print("Inpainting (diffusers) is not part of this build: skipped.")
     else:
         print("Skipping inpainting step as 'inpaint' is set to False.")
-    if no_intermediate and not refined:
-        # without the refinement stage none of the *_final artefacts exists: deleting the "intermediate" results
-        # would leave a directory with no results at all, so they are kept
-        print("no_intermediate: refinement was skipped, keeping the detector / segmentor outputs.")
-    elif no_intermediate:
+    if no_intermediate:
         keep = {"masks_final", "complete_layers", "complete_layers_rgba", "bboxes_final.json",
                 "bboxes_final.png", "segmented_sketch_final.png", "depth_map.png", "input.png"}
         for item in os.listdir(out_dir):

@@ -85,8 +85,9 @@ def test_runner_plugins_full_depth_against_oracle(dev, tmp_path, monkeypatch):
         eng.cfg.box_threshold = gcfg.box_threshold
     assert out_dir == tmp_path / "out" / "generated"            # name = basename before the FIRST dot
     assert sorted(p.name for p in out_dir.iterdir()) == ["bboxes.json", "bboxes.png", "bboxes_final.json",
-                                                         "bboxes_final.png", "input.png", "masks", "masks_cleaned",
-                                                         "segmented_sketch.png"]
+                                                         "bboxes_final.png", "depth_map.png", "input.png", "masks",
+                                                         "masks_cleaned", "masks_disjoint", "masks_final",
+                                                         "segmented_sketch.png", "segmented_sketch_final.png"]
     # D0 / D17: detector plugin output vs the oracle.  Random weights leave an ill-conditioned tail of queries whose
     # score can cross any threshold (tests/test_gdino_gpu.py), so the kept boxes are MATCHED to the oracle's 900
     # queries (nearest box) instead of being compared by position: every kept box must be an oracle query, every
@@ -131,6 +132,28 @@ def test_runner_plugins_full_depth_against_oracle(dev, tmp_path, monkeypatch):
         assert np.array_equal(np.asarray(Image.open(out_dir / "masks_cleaned" / f"mask_{i}.png")), wc)
     want_final = refine_ref.process_json_with_sketch_nms(np.asarray(pil), saved, want_clean, 0.2)
     assert json.loads((out_dir / "bboxes_final.json").read_text()) == want_final
+    # §8(f)-2 / -4 through the runner (config 5's stages): the depth map of the GPU engine against the depth oracle
+    # on the same random weights, then masks_disjoint / masks_final against the host stage re-run on the ORACLE's depth
+    from oracle import depth_ref
+    from inklayer_amd import depth as hip_depth, refine_host
+    import InkLayer.refinement.depth_sort as DS
+    dcfg = depth_ref.DepthConfig()
+    dsd = {k_: v.cpu() for k_, v in weights_init.random_depth_state_dict(hip_depth.DepthConfig(), "cuda").items()}
+    bgr = np.ascontiguousarray(np.asarray(pil)[..., ::-1])
+    ref_depth = depth_ref.infer_image(dsd, dcfg, bgr)
+    got_depth = DS.get_depth_map(str(out_dir / "input.png"))
+    rel = np.abs(got_depth - ref_depth).max() / np.abs(ref_depth).max()
+    print("runner depth map vs oracle: max-rel", rel)
+    assert got_depth.shape == (H, W) and rel < 1e-2
+    kept = want_final["kept_indices"]
+    boxes_px = refine_host.unnormalize_bboxes(want_final["bboxes"], H, W)
+    dis, sboxes, _ = refine_host.parse_masks_to_disjoint_masks([want_clean[i] for i in kept], boxes_px, np.asarray(pil), ref_depth)
+    fin = refine_host.improve_sam_masks(np.asarray(pil), dis, sboxes)
+    assert len(list((out_dir / "masks_disjoint").iterdir())) == len(dis) and len(list((out_dir / "masks_final").iterdir())) == len(fin)
+    same = all(np.array_equal(np.asarray(Image.open(out_dir / "masks_final" / f"mask_{i}.png")) > 0, np.asarray(m) > 0)
+               for i, m in enumerate(fin))
+    print("masks_final identical to the host stage on the oracle's depth:", same)
+    DS._engine = None
     DET.model = None
     SEG._engine = None
     torch.cuda.empty_cache()

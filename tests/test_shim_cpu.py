@@ -84,13 +84,18 @@ def _fake_plugins(monkeypatch):
                 "threshold": iou_threshold}
 
     monkeypatch.setattr(BF, "process_json_with_sketch_NMS", fake_nms)
+    import InkLayer.refinement.refiner as RF           # the depth model runs on the GPU: a synthetic depth map here
+    monkeypatch.setattr(RF, "get_depth_map", lambda path: np.tile(np.linspace(0, 3, Image.open(path).size[0], dtype=np.float32),
+                                                                  (Image.open(path).size[1], 1)))
 
 
 def _check_tree(out_dir, W, H):
     out_dir = Path(out_dir)
     assert sorted(p.name for p in out_dir.iterdir()) == ["bboxes.json", "bboxes.png", "bboxes_final.json",
-                                                         "bboxes_final.png", "input.png", "masks", "masks_cleaned",
-                                                         "segmented_sketch.png"]
+                                                         "bboxes_final.png", "depth_map.png", "input.png", "masks",
+                                                         "masks_cleaned", "masks_disjoint", "masks_final",
+                                                         "segmented_sketch.png", "segmented_sketch_final.png"]
+    assert Image.open(out_dir / "depth_map.png").mode == "RGB"
     fin = json.loads((out_dir / "bboxes_final.json").read_text())
     assert sorted(fin) == ["bboxes", "kept_indices", "scores", "threshold"] and fin["threshold"] == 0.2
     c0 = Image.open(out_dir / "masks_cleaned" / "mask_0.png")
@@ -116,7 +121,8 @@ def test_runner_output_tree_and_wipe(tmp_path, monkeypatch):
     assert Path(out_dir) == base / "my" and not stale.exists()
     _check_tree(out_dir, 80, 60)
     out_dir = R.run_inklayer_pipeline(str(src), str(base), no_intermediate=True)
-    _check_tree(out_dir, 80, 60)        # refinement is not part of this build: nothing final exists, results are kept
+    assert sorted(p.name for p in Path(out_dir).iterdir()) == ["bboxes_final.json", "bboxes_final.png", "depth_map.png",
+                                                                "input.png", "masks_final", "segmented_sketch_final.png"]
     with pytest.raises(NotImplementedError):
         R.run_inpaint_single_layer({}, ".", ".")
 
