@@ -1,9 +1,10 @@
-"""Mask cleanup plugin (reference: InkLayer/refinement/mask_cleaner.py), MI355X kernels underneath.
+"""Mask cleanup plugin (reference surface: InkLayer/refinement/mask_cleaner.py), MI355X kernels underneath.
 
-Same entry points: `calculate_kernel_size`, `clean_up_mask(binary_mask) -> uint8 0/255`,
-`run_clean_masks_on_sketch_dir(sketch_dir) -> <sketch_dir>/masks_cleaned`, same files written (8-bit grayscale PNGs).
-All masks of a sketch are cleaned in ONE batched GPU call; `clean_masks_in_memory` is the hand-off the runner uses so
-that the masks never have to be re-read from disk."""
+  calculate_kernel_size(image_shape, factor) -> (k, k)
+  clean_up_mask(binary_mask) -> uint8 0/255
+  run_clean_masks_on_sketch_dir(sketch_dir) -> <sketch_dir>/masks_cleaned   (8-bit grayscale PNGs, as the reference)
+All masks of a sketch are cleaned in ONE batched GPU call (`ink_mask_cleanup`); `clean_masks_in_memory` is the hand-off
+the runner uses, so the masks are never re-read from disk."""
 import glob
 import os
 
@@ -12,22 +13,21 @@ from PIL import Image
 
 
 def calculate_kernel_size(image_shape, factor=0.025):
-    kernel_size = int(min(image_shape) * factor)
-    kernel_size = kernel_size if kernel_size % 2 != 0 else kernel_size + 1
-    return (kernel_size, kernel_size)
+    from inklayer_amd import refine
+    k = refine.calculate_kernel_size(image_shape, factor)
+    return (k, k)
 
 
 def clean_masks_in_memory(masks):
-    """masks: sequence of HxW arrays (bool, or uint8 with > 127 = foreground) of ONE size -> uint8 [n, H, W] 0/255
-    numpy array (cleaned), computed on the GPU."""
+    """A sequence of equally sized HxW masks (bool, or uint8 where > 127 is foreground) -> cleaned uint8 [n, H, W]
+    (0 / 255), computed on the GPU."""
     import torch
     from inklayer_amd import refine
     if len(masks) == 0:
         return np.zeros((0, 0, 0), np.uint8)
-    arr = np.stack([np.asarray(m) for m in masks])
-    arr = arr.astype(np.uint8) * 255 if arr.dtype == np.bool_ else arr.astype(np.uint8)
-    dev = torch.from_numpy(np.ascontiguousarray(arr)).to("cuda")
-    return refine.clean_masks(dev).cpu().numpy()
+    stack = np.stack([np.asarray(m) for m in masks])
+    stack = stack.astype(np.uint8) * 255 if stack.dtype == np.bool_ else stack.astype(np.uint8)
+    return refine.clean_masks(torch.from_numpy(np.ascontiguousarray(stack)).to("cuda")).cpu().numpy()
 
 
 def clean_up_mask(binary_mask):
@@ -35,20 +35,20 @@ def clean_up_mask(binary_mask):
 
 
 def run_clean_masks_on_sketch_dir(sketch_dir, masks=None, cleaned=None):
-    """`masks` / `cleaned` (optional, this build's extension): the raw or already cleaned masks in memory; otherwise
+    """`masks` / `cleaned` (this build's extension): raw or already cleaned masks held in memory; without them
     masks/mask_i.png are read."""
-    sam_masks_dir = f"{sketch_dir}/masks"
-    if not os.path.exists(sam_masks_dir):
-        print(f"Skipping {sam_masks_dir}")
-        return
-    num_masks = len(glob.glob(f"{sam_masks_dir}/mask_*.png"))
-    out_dir = f"{sketch_dir}/masks_cleaned"
-    os.makedirs(out_dir, exist_ok=True)
+    src = os.path.join(sketch_dir, "masks")
+    if not os.path.isdir(src):
+        print(f"{src} is missing: nothing to clean")
+        return None
+    dst = os.path.join(sketch_dir, "masks_cleaned")
+    os.makedirs(dst, exist_ok=True)
     if cleaned is None:
         if masks is None:
-            masks = [np.asarray(Image.open(f"{sam_masks_dir}/mask_{i}.png").convert("L")) for i in range(num_masks)]
+            count = len(glob.glob(os.path.join(src, "mask_*.png")))
+            masks = [np.asarray(Image.open(os.path.join(src, f"mask_{i}.png")).convert("L")) for i in range(count)]
         cleaned = clean_masks_in_memory(masks)
-    for i in range(len(cleaned)):
-        Image.fromarray(cleaned[i], "L").save(f"{out_dir}/mask_{i}.png")
-    print(f"Processed {num_masks} masks in {sam_masks_dir}")
-    return out_dir
+    for i, m in enumerate(cleaned):
+        Image.fromarray(m, "L").save(os.path.join(dst, f"mask_{i}.png"))
+    print(f"cleaned {len(cleaned)} masks -> {dst}")
+    return dst
