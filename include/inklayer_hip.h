@@ -78,10 +78,15 @@ int ink_gemm_query_variant(int32_t M, int32_t N, int32_t K);
  * (LayerNorm2d + GELU of SA/modeling/mask_decoder.py:54-56).
  * split = 1: out_f16 rows are SPLIT-f16 operands [hi | lo*64 | hi/64] of 3*C columns (ldo >= 3*C, out_f32 NULL),
  * see ink_add_split_f16.
+ * add (f32 or NULL, not together with gather): the row normalised is x[r] + add[add_batch_rows[r / rows_per_batch] +
+ * r % rows_per_batch] (add_batch_rows NULL: add[r]) - the residual add of SA/modeling/transformer.py:180-181 when the
+ * image keys are still shared by all boxes of an image (no per-box copy of them is ever made).
  * --------------------------------------------------------------------- */
 int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamma, const float* beta,
                        float eps, const int32_t* gather, int32_t rows_out, int32_t C,
-                       void* out_f16, float* out_f32, int64_t ldo, int32_t act, int32_t split, void* stream);
+                       void* out_f16, float* out_f32, int64_t ldo, int32_t act, int32_t split,
+                       const float* add, int64_t ld_add, const int32_t* add_batch_rows, int32_t rows_per_batch,
+                       void* stream);
 
 /* f32 -> f16 conversion with optional broadcast addend:  out[i] = f16(a[i] + b[i % n_b])
  * (b may be NULL).  n % 4 == 0, n_b % 4 == 0, n % n_b == 0.  Used for the "x + pos" operands of
@@ -272,23 +277,25 @@ int ink_biattn_fusion(const void* QV_f16, const void* KL_f16, int32_t B, int32_t
 /* softmax(scale q k^T [+ blocked -> -inf]) v against n_k <= 16 keys; head h at columns
  * [h*hd,(h+1)*hd), hd in {16,32,64}; blocked: u8 [n_q, n_k] (1 = not allowed) or NULL.  io_f32 = 0: Q/K/V/O are
  * f16 rows, 1: f32 rows (ld* in elements either way; the math is f32 in both).  q_batch_rows (int32 [B] or NULL):
- * first Q row of batch entry b (default b*n_q); keys and the output are dense.
+ * first Q row of batch entry b (default b*n_q); keys and the output are dense.  q_add (f32 [n_q, n_heads*hd] or NULL) is
+ * added to the query rows by position (the per-position constant pe.W of a projection of x + pe).
  * Text self-attention (transformer_vanilla.py:114-116), decoder text cross-attention (transformer.py:893-900) and,
  * with f32 rows, the SAM mask decoder's token self-attention and image -> token attention
  * (SA/modeling/transformer.py:151-182: 7 x 7 and 4096 x 7). */
 int ink_attn_fewkeys(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                      int32_t B, int32_t n_q, int32_t n_k, int32_t n_heads, int32_t head_dim, float scale,
-                     const uint8_t* blocked, const int32_t* q_batch_rows, int32_t io_f32, void* O, int64_t ldo,
-                     void* stream);
+                     const uint8_t* blocked, const int32_t* q_batch_rows, const float* q_add, int32_t io_f32, void* O,
+                     int64_t ldo, void* stream);
 
 /* softmax(scale q k^T) v for n_q <= 8 queries per batch entry against MANY keys (SAM decoder tokens ->
  * image: 7 x 4096, SA/modeling/transformer.py:163-168): head h at columns [h*hd,(h+1)*hd),
  * hd in {16,32}; q_batch_rows / kv_batch_rows as in InkAttn; O dense [n_batch*n_q, ..].  io_f32 = 0: f16 rows,
- * 1: f32 rows (head_dim 16 with n_heads % 4 == 0 only). */
+ * 1: f32 rows (head_dim 16 with n_heads % 4 == 0 only).  k_add (f32 [n_k, n_heads*hd] or NULL, f32 rows only) is
+ * added to the key rows by key position. */
 int ink_attn_fewq(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                   int32_t n_batch, int32_t n_q, int32_t n_k, int32_t n_heads, int32_t head_dim, float scale,
-                  const int32_t* q_batch_rows, const int32_t* kv_batch_rows, int32_t io_f32, void* O, int64_t ldo,
-                  void* stream);
+                  const int32_t* q_batch_rows, const int32_t* kv_batch_rows, const float* k_add, int32_t io_f32, void* O,
+                  int64_t ldo, void* stream);
 
 /* Two-stage query selection (transformer.py:293-300): indices of the K largest max_t logits[b,s,t],
  * descending, ties -> lower index.  logits f32 [B,S,T]; out_idx int32 [B,K].  S <= 16384 is one LDS

@@ -45,7 +45,7 @@ SIGNATURES = {
     "ink_gemm_set_variant": [c_int],
     "ink_gemm_query_variant": [c_int, c_int, c_int],
     "ink_layernorm_rows": [c_void_p, c_i64, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
-                           c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p],
+                           c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p, c_int, c_void_p],
     "ink_add_split_f16": [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p],
     "ink_add_cvt_f16": [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p],
     "ink_add_f32": [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p],
@@ -73,9 +73,9 @@ SIGNATURES = {
     "ink_biattn_fusion": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                           c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "ink_attn_fewkeys": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int,
-                         c_float, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p],
+                         c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p],
     "ink_attn_fewq": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int,
-                      c_float, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p],
+                      c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p],
     "ink_topk_rowmax": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ink_sine_embed4": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "ink_box_refine": [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p],

@@ -386,6 +386,7 @@ __global__ __launch_bounds__(256) void attn_fewkeys_kernel(const T* __restrict__
                                                            int n_q, int n_k, int n_heads, float scale,
                                                            const uint8_t* __restrict__ blocked,
                                                            const int32_t* __restrict__ q_rows,
+                                                           const float* __restrict__ q_add,
                                                            T* __restrict__ O, int64_t ldo) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (int64_t)B * n_q * n_heads) return;
@@ -396,6 +397,11 @@ __global__ __launch_bounds__(256) void attn_fewkeys_kernel(const T* __restrict__
   const T* qp = Q + (q_rows ? (int64_t)q_rows[b] + q : bq) * ldq + h * HD;
 #pragma unroll
   for (int i = 0; i < HD / 8; ++i) load8(qp + 8 * i, qv + 8 * i);
+  if (q_add) {   // per-position constant of the query projection (the (x + pe) W = x W + pe W split, sam.py)
+    const float* ap = q_add + ((int64_t)q * n_heads + h) * HD;
+#pragma unroll
+    for (int i = 0; i < HD; ++i) qv[i] += ap[i];
+  }
   float sc[16];
   float mx = -3.0e38f;
   for (int t = 0; t < n_k; ++t) {
@@ -521,6 +527,7 @@ __global__ __launch_bounds__(256) void attn_fewq16_kernel(const T* __restrict__ 
                                                           int n_k, int n_heads, float scale,
                                                           const int32_t* __restrict__ q_rows,
                                                           const int32_t* __restrict__ kv_rows,
+                                                          const float* __restrict__ k_add,
                                                           T* __restrict__ O, int64_t ldo) {
   constexpr int HD = 16, HB = 4, TK = 64;
   constexpr int ROWE = HB * HD;                      // elements of K (or V) per key and 4-head group (one 128-B line in f16)
@@ -561,6 +568,14 @@ __global__ __launch_bounds__(256) void attn_fewq16_kernel(const T* __restrict__ 
       if (t0 + row < n_k) {
         rk[u] = *(const u32x4*)(K + (k0 + t0 + row) * ldk + h0 * HD + col * CH);
         rv[u] = *(const u32x4*)(V + (k0 + t0 + row) * ldv + h0 * HD + col * CH);
+        if constexpr (sizeof(T) == 4) {
+          if (k_add) {   // per-key constant of the key projection, [n_k, n_heads*HD] f32
+            const f32x4 ad = *(const f32x4*)(k_add + (int64_t)(t0 + row) * n_heads * HD + h0 * HD + col * CH);
+            f32x4 kv4 = __builtin_bit_cast(f32x4, rk[u]);
+            kv4 += ad;
+            rk[u] = __builtin_bit_cast(u32x4, kv4);
+          }
+        }
       }
     }
     __syncthreads();                                   // previous tile consumed
@@ -816,17 +831,18 @@ extern "C" int ink_biattn_fusion(const void* QV_f16, const void* KL_f16, int32_t
 extern "C" int ink_attn_fewkeys(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V,
                                 int64_t ldv, int32_t B, int32_t n_q, int32_t n_k, int32_t n_heads,
                                 int32_t head_dim, float scale, const uint8_t* blocked,
-                                const int32_t* q_batch_rows, int32_t io_f32, void* O, int64_t ldo,
-                                void* stream) {
+                                const int32_t* q_batch_rows, const float* q_add, int32_t io_f32, void* O,
+                                int64_t ldo, void* stream) {
   INK_CHECK_ARG(Q && K && V && O && B > 0 && n_q > 0 && n_k > 0 && n_k <= 16 && n_heads > 0);
   INK_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0);
   INK_CHECK_ARG(io_f32 == 0 || io_f32 == 1);
+  INK_CHECK_ARG(!q_add || (((uintptr_t)q_add & 15) == 0));
   const int64_t total = (int64_t)B * n_q * n_heads;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define INK_FEWKEYS(HD, T)                                                                                     \
   hipLaunchKernelGGL((attn_fewkeys_kernel<HD, T>), grid, block, 0, s, (const T*)Q, ldq, (const T*)K, ldk,      \
-                     (const T*)V, ldv, B, n_q, n_k, n_heads, scale, blocked, q_batch_rows, (T*)O, ldo)
+                     (const T*)V, ldv, B, n_q, n_k, n_heads, scale, blocked, q_batch_rows, q_add, (T*)O, ldo)
   if (head_dim == 32 && !io_f32) INK_FEWKEYS(32, f16);
   else if (head_dim == 64 && !io_f32) INK_FEWKEYS(64, f16);
   else if (head_dim == 16 && !io_f32) INK_FEWKEYS(16, f16);
@@ -840,20 +856,21 @@ extern "C" int ink_attn_fewkeys(const void* Q, int64_t ldq, const void* K, int64
 extern "C" int ink_attn_fewq(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                              int32_t n_batch, int32_t n_q, int32_t n_k, int32_t n_heads, int32_t head_dim,
                              float scale, const int32_t* q_batch_rows, const int32_t* kv_batch_rows,
-                             int32_t io_f32, void* O, int64_t ldo, void* stream) {
+                             const float* k_add, int32_t io_f32, void* O, int64_t ldo, void* stream) {
   INK_CHECK_ARG(Q && K && V && O && n_batch > 0 && n_q > 0 && n_q <= 8 && n_k > 0 && n_heads > 0);
   INK_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0);
   INK_CHECK_ARG(io_f32 == 0 || (io_f32 == 1 && head_dim == 16 && n_heads % 4 == 0));
+  INK_CHECK_ARG(!k_add || (io_f32 == 1 && ((uintptr_t)k_add & 15) == 0));
   const dim3 grid(n_batch * n_heads), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (head_dim == 16 && n_heads % 4 == 0 && io_f32) {
     hipLaunchKernelGGL(attn_fewq16_kernel<float>, dim3(n_batch * (n_heads / 4)), block, 0, s, (const float*)Q, ldq,
                        (const float*)K, ldk, (const float*)V, ldv, n_q, n_k, n_heads, scale, q_batch_rows,
-                       kv_batch_rows, (float*)O, ldo);
+                       kv_batch_rows, k_add, (float*)O, ldo);
   } else if (head_dim == 16 && n_heads % 4 == 0) {
     hipLaunchKernelGGL(attn_fewq16_kernel<f16>, dim3(n_batch * (n_heads / 4)), block, 0, s, (const f16*)Q, ldq,
                        (const f16*)K, ldk, (const f16*)V, ldv, n_q, n_k, n_heads, scale, q_batch_rows, kv_batch_rows,
-                       (f16*)O, ldo);
+                       (const float*)nullptr, (f16*)O, ldo);
   } else if (head_dim == 16) {
     hipLaunchKernelGGL(attn_fewq_kernel<16>, grid, block, 0, s, (const f16*)Q, ldq, (const f16*)K, ldk,
                        (const f16*)V, ldv, n_q, n_k, n_heads, scale, q_batch_rows, kv_batch_rows, (f16*)O, ldo);

@@ -27,7 +27,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, const int32_t* __restrict__ gather, int rows_out,
-    int C, f16* __restrict__ out_h, float* __restrict__ out_f, int64_t ldo, int act, int split) {
+    int C, f16* __restrict__ out_h, float* __restrict__ out_f, int64_t ldo, int act, int split,
+    const float* __restrict__ add, int64_t ld_add, const int32_t* __restrict__ add_batch_rows, int rows_per_batch) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows_out) return;
@@ -42,12 +43,20 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
     return;
   }
   const float* xr = x + (int64_t)src * ldx;
+  // optional addend row: add[add_batch_rows[b] + i] for row = b * rows_per_batch + i (a per-batch-entry gather of a
+  // shared tensor: the mask decoder's "keys + attn_out" where the keys are still one copy per IMAGE, sam.py)
+  const float* ar = nullptr;
+  if (add) {
+    const int b = row / rows_per_batch, i = row - b * rows_per_batch;
+    ar = add + ((int64_t)(add_batch_rows ? add_batch_rows[b] : b * rows_per_batch) + i) * ld_add;
+  }
   f32x4 r[NV];
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int v = lane + 64 * j;
     r[j] = v < nv ? *(const f32x4*)(xr + v * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ar && v < nv) r[j] += *(const f32x4*)(ar + v * 4);
     s += (r[j][0] + r[j][1]) + (r[j][2] + r[j][3]);
   }
   const float mean = wave_sum(s) / (float)C;
@@ -112,8 +121,10 @@ __global__ __launch_bounds__(256) void add_cvt_f16_kernel(const float* __restric
 extern "C" int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamma,
                                   const float* beta, float eps, const int32_t* gather,
                                   int32_t rows_out, int32_t C, void* out_f16, float* out_f32,
-                                  int64_t ldo, int32_t act, int32_t split, void* stream) {
+                                  int64_t ldo, int32_t act, int32_t split, const float* add, int64_t ld_add,
+                                  const int32_t* add_batch_rows, int32_t rows_per_batch, void* stream) {
   INK_CHECK_ARG(x && (out_f16 || out_f32));
+  INK_CHECK_ARG(!add || (!gather && rows_per_batch > 0 && ld_add >= C && ld_add % 4 == 0));
   INK_CHECK_ARG(split == 0 || (split == 1 && out_f16 && !out_f32 && ldo >= 3 * (int64_t)C));
   INK_CHECK_ARG(act == INK_ACT_NONE || act == INK_ACT_GELU);
   INK_CHECK_ARG(rows_out > 0 && C > 0 && C % 4 == 0 && C <= 2048);
@@ -123,7 +134,8 @@ extern "C" int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamm
   const int nv = (C / 4 + 63) / 64;
 #define INK_LN(NV)                                                                          \
   hipLaunchKernelGGL(layernorm_rows_kernel<NV>, grid, block, 0, s, x, ldx, gamma, beta, eps, \
-                     gather, rows_out, C, (f16*)out_f16, out_f32, ldo, act, split)
+                     gather, rows_out, C, (f16*)out_f16, out_f32, ldo, act, split, add, ld_add, add_batch_rows, \
+                     rows_per_batch)
   switch (nv) {
     case 1: INK_LN(1); break;
     case 2: INK_LN(2); break;

@@ -108,7 +108,8 @@ def layernorm_rows(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optiona
                    eps: float, *, gather: Optional[torch.Tensor] = None,
                    out_dtype: torch.dtype = F16, out: Optional[torch.Tensor] = None,
                    out2: Optional[torch.Tensor] = None, act: Optional[str] = None,
-                   split: bool = False) -> torch.Tensor:
+                   split: bool = False, add: Optional[torch.Tensor] = None,
+                   add_batch_rows: Optional[torch.Tensor] = None, rows_per_batch: int = 0) -> torch.Tensor:
     """LayerNorm over the last dim of f32 x [R, C]; optional row gather (-1 -> zero row).
     `out2` (the other of f16/f32, same shape/stride) receives a second copy in the same pass.
     split=True: the f16 output is a split-f16 GEMM operand [R, 3C] (see add_split_f16)."""
@@ -131,9 +132,18 @@ def layernorm_rows(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optiona
             of = out2.data_ptr()
     if gather is not None:
         assert gather.dtype == torch.int32
+    if add is not None:
+        # LN(x[r] + add[add_batch_rows[r // rows_per_batch] + r % rows_per_batch]) (add_batch_rows None: add[r])
+        assert gather is None and add.dtype == F32 and add.dim() == 2 and add.stride(1) == 1 and add.shape[1] == Cdim
+        if add_batch_rows is not None:
+            assert add_batch_rows.dtype == torch.int32 and add_batch_rows.is_cuda and rows_per_batch > 0
+            assert add_batch_rows.numel() * rows_per_batch == rows
+        else:
+            rows_per_batch = rows
     check(_lib.lib().ink_layernorm_rows(x.data_ptr(), x.stride(0), _p(gamma), _p(beta), eps,
                                         _p(gather), rows, Cdim, oh, of, out.stride(0), ACT[act], int(split),
-                                        _stream()), "ink_layernorm_rows")
+                                        _p(add), add.stride(0) if add is not None else 0, _p(add_batch_rows),
+                                        rows_per_batch, _stream()), "ink_layernorm_rows")
     return out
 
 
@@ -474,7 +484,7 @@ def biattn_fusion(qv16: torch.Tensor, kl16: torch.Tensor, B: int, S: int, T: int
 
 def attn_fewkeys(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, B: int, n_heads: int, head_dim: int,
                  scale: float, blocked: Optional[torch.Tensor] = None, n_q: Optional[int] = None,
-                 q_batch_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 q_batch_rows: Optional[torch.Tensor] = None, q_add: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Attention against n_k <= 16 keys per batch entry; q/k/v/out are all f16 or all f32 rows (f32 math either
     way).  q_batch_rows: first q row of each batch entry (then n_q must be given)."""
     io = q.dtype
@@ -488,24 +498,28 @@ def attn_fewkeys(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, B: int, n
         assert blocked.dtype == torch.uint8 and blocked.is_contiguous() and blocked.shape == (n_q, n_k)
     if q_batch_rows is not None:
         assert q_batch_rows.dtype == torch.int32 and q_batch_rows.numel() == B and q_batch_rows.is_cuda
+    if q_add is not None:
+        assert q_add.dtype == F32 and q_add.is_contiguous() and tuple(q_add.shape) == (n_q, n_heads * head_dim)
     check(_lib.lib().ink_attn_fewkeys(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
                                       v.stride(0), B, n_q, n_k, n_heads, head_dim, scale, _p(blocked),
-                                      _p(q_batch_rows), int(io == F32), out.data_ptr(), out.stride(0), _stream()),
+                                      _p(q_batch_rows), _p(q_add), int(io == F32), out.data_ptr(), out.stride(0), _stream()),
           "ink_attn_fewkeys")
     return out
 
 
 def attn_fewq(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: int, n_heads: int, head_dim: int,
               scale: float, n_q: int, n_k: int, q_batch_rows: Optional[torch.Tensor] = None,
-              kv_batch_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+              kv_batch_rows: Optional[torch.Tensor] = None, k_add: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Few queries (<= 8) against many keys; same row conventions as flash_attn.  q/k/v/out all f16 or all f32."""
     io = q.dtype
     for t in (q, k, v):
         assert t.dtype == io and io in (F16, F32) and t.dim() == 2 and t.stride(1) == 1
     out = torch.empty((n_batch * n_q, n_heads * head_dim), device=q.device, dtype=io)
+    if k_add is not None:
+        assert io == F32 and k_add.dtype == F32 and k_add.is_contiguous() and tuple(k_add.shape) == (n_k, n_heads * head_dim)
     check(_lib.lib().ink_attn_fewq(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                    n_batch, n_q, n_k, n_heads, head_dim, scale, _p(q_batch_rows),
-                                   _p(kv_batch_rows), int(io == F32), out.data_ptr(), out.stride(0), _stream()),
+                                   _p(kv_batch_rows), _p(k_add), int(io == F32), out.data_ptr(), out.stride(0), _stream()),
           "ink_attn_fewq")
     return out
 

@@ -227,6 +227,19 @@ class SamEngine:
             w[f"d{i}.lin1.ws"] = ops.split_weight(m(p + "mlp.lin1.weight"))
             w[f"d{i}.lin2.ws"] = ops.split_weight(m(p + "mlp.lin2.weight"))
         attn("dfin", t + "final_attn_token_to_image")
+        # (keys + pe) W = keys W + pe W: ONE split pass of the image keys feeds the token->image k and v projections and
+        # the image->token q projection (one GEMM, N = 384); pe W is a per-position constant [T, 128] that the attention
+        # kernels add (k_add / q_add).  The constants come from the same split-f16 GEMM (fp32-grade).
+        pe_split = ops.add_split_f16(self.dense_pe)
+        for i in range(cfg.dec_depth):
+            d = f"d{i}"
+            w[d + ".kvq.ws"] = torch.cat([w[d + ".t2i.k_proj.ws"], w[d + ".t2i.v_proj.ws"], w[d + ".i2t.q_proj.ws"]]).contiguous()
+            w[d + ".kvq.b"] = torch.cat([w[d + ".t2i.k_proj.b"], w[d + ".t2i.v_proj.b"], w[d + ".i2t.q_proj.b"]]).contiguous()
+            w[d + ".t2i.k_pe"] = ops.gemm(pe_split, w[d + ".t2i.k_proj.ws"]).contiguous()
+            w[d + ".i2t.q_pe"] = ops.gemm(pe_split, w[d + ".i2t.q_proj.ws"]).contiguous()
+        w["dfin.kv.ws"] = torch.cat([w["dfin.k_proj.ws"], w["dfin.v_proj.ws"]]).contiguous()
+        w["dfin.kv.b"] = torch.cat([w["dfin.k_proj.b"], w["dfin.v_proj.b"]]).contiguous()
+        w["dfin.k_pe"] = ops.gemm(pe_split, w["dfin.k_proj.ws"]).contiguous()
         u = "mask_decoder.output_upscaling."
         w["up0.ws"] = ops.split_weight(m(u + "0.weight").permute(2, 3, 1, 0).reshape(4 * (E // 4), E))
         w["up3.ws"] = ops.split_weight(m(u + "3.weight").permute(2, 3, 1, 0).reshape(4 * (E // 8), E // 4))
@@ -480,19 +493,17 @@ class SamEngine:
         qpe = tokens.view(n * NT, E)
         iob = torch.as_tensor(list(img_of_box), dtype=torch.int64)
         img_rows = _to_dev_async((iob * T).to(torch.int32), dev)
-        iob_dev = _to_dev_async(iob, dev)
         keys = ops.add_f32(emb.reshape(B * T, E).contiguous(), w["no_mask"])      # [B*T, E], shared per image
-        kpe = self.dense_pe
         shared = True                                       # keys still one copy per IMAGE (layer 0)
         queries = qpe
         sc32, sc16 = 1.0 / math.sqrt(32), 1.0 / math.sqrt(16)
 
-        def t2i(name, queries, keys_pe_s, keys_s, residual):
+        Eh = E // 2                                           # internal width of the cross attentions (128)
+
+        def t2i_attend(name, queries, k, v, k_pe, residual):
             q = lin(SP(queries, qpe), name + ".q_proj")
-            k = lin(keys_pe_s, name + ".k_proj")
-            v = lin(keys_s, name + ".v_proj")
             a = ops.attn_fewq(q, k, v, n_batch=n, n_heads=Hh, head_dim=16, scale=sc16, n_q=NT, n_k=T,
-                              kv_batch_rows=img_rows if shared else None)
+                              kv_batch_rows=img_rows if shared else None, k_add=k_pe)
             return lin(SP(a), name + ".out_proj", residual=residual)
 
         for i in range(cfg.dec_depth):
@@ -509,28 +520,33 @@ class SamEngine:
                 a = ops.attn_fewkeys(qk[:, :E], qk[:, E:], v, B=n, n_heads=Hh, head_dim=32, scale=sc32)
                 queries = lin(SP(a), d + ".self.out_proj", residual=queries)
             queries = ops.layernorm_rows(queries, w[d + ".norm1.w"], w[d + ".norm1.b"], 1e-5, out_dtype=F32)
-            # (2) tokens -> image
-            kps, ks = SP(keys, kpe), SP(keys)
-            queries = ops.layernorm_rows(t2i(d + ".t2i", queries, kps, ks, queries),
+            # image-side projections of this layer from ONE split pass of the keys: [k_t2i | v_t2i | q_i2t]
+            kvq = ops.gemm(SP(keys), w[d + ".kvq.ws"], w[d + ".kvq.b"])             # [B*T or n*T, 384] f32
+            # (2) tokens -> image  (k = (keys + pe) Wk = kvq[:, :128] + pe Wk, added inside the attention)
+            queries = ops.layernorm_rows(t2i_attend(d + ".t2i", queries, kvq[:, :Eh], kvq[:, Eh:2 * Eh],
+                                                    w[d + ".t2i.k_pe"], queries),
                                          w[d + ".norm2.w"], w[d + ".norm2.b"], 1e-5, out_dtype=F32)
             # (3) token MLP
             hmid = lin(SP(queries), d + ".lin1", act="relu")
             queries = ops.layernorm_rows(lin(SP(hmid), d + ".lin2", residual=queries),
                                          w[d + ".norm3.w"], w[d + ".norm3.b"], 1e-5, out_dtype=F32)
-            # (4) image -> tokens: q = keys + key_pe (the operand of step 2), k = queries + qpe, v = queries
-            iq = lin(kps, d + ".i2t.q_proj")                                     # [B*T or n*T, 128]
+            # (4) image -> tokens: q = (keys + pe) Wq = kvq[:, 256:] + pe Wq, k = queries + qpe, v = queries
             ik = lin(SP(queries, qpe), d + ".i2t.k_proj")
             iv = lin(SP(queries), d + ".i2t.v_proj")
-            a = ops.attn_fewkeys(iq, ik, iv, B=n, n_heads=Hh, head_dim=16, scale=sc16, n_q=T,
-                                 q_batch_rows=img_rows if shared else None)       # [n*T, 128]
+            a = ops.attn_fewkeys(kvq[:, 2 * Eh:], ik, iv, B=n, n_heads=Hh, head_dim=16, scale=sc16, n_q=T,
+                                 q_batch_rows=img_rows if shared else None, q_add=w[d + ".i2t.q_pe"])   # [n*T, 128]
             if shared:
-                # per-box copy of the image keys (repeat_interleave of mask_decoder.py:124; a pure memory copy)
-                keys = keys.view(B, T * E).index_select(0, iob_dev).view(n * T, E)
+                # keys are still one copy per IMAGE: the residual add happens inside the LayerNorm through a per-box
+                # row gather - no per-box copy of the image keys (repeat_interleave of mask_decoder.py:124) is made
+                keys = ops.layernorm_rows(lin(SP(a), d + ".i2t.out_proj"), w[d + ".norm4.w"], w[d + ".norm4.b"], 1e-5,
+                                          out_dtype=F32, add=keys, add_batch_rows=img_rows, rows_per_batch=T)
                 shared = False
-            keys = ops.layernorm_rows(lin(SP(a), d + ".i2t.out_proj", residual=keys),
-                                      w[d + ".norm4.w"], w[d + ".norm4.b"], 1e-5, out_dtype=F32)
+            else:
+                keys = ops.layernorm_rows(lin(SP(a), d + ".i2t.out_proj", residual=keys),
+                                          w[d + ".norm4.w"], w[d + ".norm4.b"], 1e-5, out_dtype=F32)
         ks = SP(keys)
-        queries = ops.layernorm_rows(t2i("dfin", queries, SP(keys, kpe), ks, queries),
+        kv = ops.gemm(ks, w["dfin.kv.ws"], w["dfin.kv.b"])
+        queries = ops.layernorm_rows(t2i_attend("dfin", queries, kv[:, :Eh], kv[:, Eh:], w["dfin.k_pe"], queries),
                                      w["dfin.norm.w"], w["dfin.norm.b"], 1e-5, out_dtype=F32)
         hs = queries.view(n, NT, E)
 

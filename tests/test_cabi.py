@@ -42,7 +42,7 @@ def test_bad_arguments_are_rejected_without_launch():
     p.lda = p.ldw = 24
     p.ldc = 8
     assert l.ink_gemm_f16(ctypes.byref(p), None) == 1
-    assert l.ink_layernorm_rows(None, 0, None, None, 1e-6, None, 1, 4, None, None, 4, 0, 0, None) == 1
+    assert l.ink_layernorm_rows(None, 0, None, None, 1e-6, None, 1, 4, None, None, 4, 0, 0, None, 0, None, 0, None) == 1
     assert l.ink_add_split_f16(16, None, 0, 16, 8, 3, None) == 1            # C % 4 != 0
 
 

@@ -103,3 +103,41 @@ def test_attn_fewq_f32_rows(dev):
             ref = _attn_ref(qb, kb, vb, 1 / math.sqrt(hd)).transpose(0, 1).reshape(nq, E)
             got = out[b * nq:(b + 1) * nq].double().cpu()
             assert (got - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_position_constants_and_gathered_residual(dev):
+    """(x + pe) W = x W + pe W: attn_fewq's k_add / attn_fewkeys' q_add (per-position constants added inside the
+    kernels) and layernorm_rows' gathered residual add (the image keys shared by the boxes of an image)."""
+    from inklayer_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(17)
+    heads, hd, nq, nk, n = 8, 16, 7, 4096, 3
+    E = heads * hd
+    q = torch.randn(n * nq, E, generator=g)
+    k = torch.randn(n * nk, E, generator=g)
+    v = torch.randn(n * nk, E, generator=g)
+    kadd = torch.randn(nk, E, generator=g)
+    a = ops.attn_fewq(q.to(dev), k.to(dev), v.to(dev), n_batch=n, n_heads=heads, head_dim=hd, scale=0.25, n_q=nq, n_k=nk,
+                      k_add=kadd.to(dev))
+    b = ops.attn_fewq(q.to(dev), (k.view(n, nk, E) + kadd).reshape(n * nk, E).contiguous().to(dev), v.to(dev), n_batch=n,
+                      n_heads=heads, head_dim=hd, scale=0.25, n_q=nq, n_k=nk)
+    assert (a - b).abs().max().item() < 1e-6
+    T = 512
+    qi = torch.randn(2 * T, E, generator=g)
+    kk = torch.randn(n * nq, E, generator=g)
+    vv = torch.randn(n * nq, E, generator=g)
+    qadd = torch.randn(T, E, generator=g)
+    rows = torch.tensor([T, 0, T], dtype=torch.int32, device=dev)
+    a = ops.attn_fewkeys(qi.to(dev), kk.to(dev), vv.to(dev), B=n, n_heads=heads, head_dim=hd, scale=0.25, n_q=T,
+                         q_batch_rows=rows, q_add=qadd.to(dev))
+    b = ops.attn_fewkeys((qi.view(2, T, E) + qadd).reshape(2 * T, E).contiguous().to(dev), kk.to(dev), vv.to(dev), B=n,
+                         n_heads=heads, head_dim=hd, scale=0.25, n_q=T, q_batch_rows=rows)
+    assert (a - b).abs().max().item() < 1e-6
+    # LayerNorm(x[r] + add[rows[r // T] + r % T])
+    x = torch.randn(n * T, 256, generator=g)
+    add = torch.randn(2 * T, 256, generator=g)
+    gam, bet = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    got = ops.layernorm_rows(x.to(dev), gam.to(dev), bet.to(dev), 1e-5, out_dtype=torch.float32, add=add.to(dev),
+                             add_batch_rows=rows, rows_per_batch=T)
+    full = x.view(n, T, 256) + add.view(2, T, 256)[[1, 0, 1]]
+    ref = torch.nn.functional.layer_norm(full.double(), (256,), gam.double(), bet.double(), 1e-5).reshape(n * T, 256)
+    assert (got.double().cpu() - ref).abs().max().item() < 2e-5
