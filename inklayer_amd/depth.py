@@ -80,7 +80,7 @@ class DepthEngine:
             return (t.reshape(shape) if shape is not None else t).to(F16).contiguous()
 
         def f(name):
-            return m32(name).contiguous()
+            return ops.own_f32(sd[name], dev)
 
         # ---- ViT
         self.KP = -(-3 * P * P // 32) * 32                       # 588 -> 608 columns per split segment

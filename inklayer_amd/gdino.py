@@ -231,7 +231,7 @@ class GDinoEngine:
             return (t.reshape(shape) if shape is not None else t).to(dev, F16).contiguous()
 
         def f(name):
-            return sd[name].detach().to(dev, F32).contiguous()
+            return ops.own_f32(sd[name], dev)
 
         def lin(dst, src):
             w[dst + ".w"], w[dst + ".b"] = h(src + ".weight"), f(src + ".bias")

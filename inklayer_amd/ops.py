@@ -49,6 +49,16 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def own_f32(t: torch.Tensor, dev) -> torch.Tensor:
+    """An engine-owned contiguous f32 copy of a parameter on `dev`.  A tensor that is only a VIEW into a larger
+    storage (e.g. a slice of dist.broadcast_state_dict's 1 GiB flat buckets) is cloned, so that the engines do not
+    keep those buckets alive through a few kilobytes of biases and norm weights."""
+    t = t.detach().to(dev, F32).contiguous()
+    if t.untyped_storage().nbytes() > t.numel() * t.element_size():
+        t = t.clone()
+    return t
+
+
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     if t is None:
         return None

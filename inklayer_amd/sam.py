@@ -110,7 +110,7 @@ class SamEngine:
             return t.to(dev, F16).contiguous()
 
         def f(name):  # vector / table -> f32
-            return sd[name].detach().to(dev, F32).contiguous()
+            return ops.own_f32(sd[name], dev)
 
         self.w: Dict[str, torch.Tensor] = {}
         w = self.w

@@ -125,3 +125,16 @@ def test_bench_self_launch_path_is_taken_without_touching_the_gpu(monkeypatch):
         bench.main()
     assert e.value.code == 0 and seen["world"] == 2
     assert seen["cmd"][0] == sys.executable and seen["cmd"][1].endswith("bench.py") and "--gpus" in seen["cmd"]
+
+
+def test_engines_do_not_pin_broadcast_buckets():
+    """receivers of broadcast_state_dict get VIEWS into <= 1 GiB flat buckets; an engine parameter must be an
+    owned copy (ops.own_f32), or a few KB of biases keep the whole bucket alive."""
+    from inklayer_amd import ops
+    flat = torch.zeros(100_000)
+    view = flat[40:52].view(3, 4)
+    owned = ops.own_f32(view, "cpu")
+    assert torch.equal(owned, view) and owned.untyped_storage().nbytes() == 48
+    whole = torch.ones(3, 4)
+    assert ops.own_f32(whole, "cpu").data_ptr() == whole.data_ptr()          # already owns its storage: no copy
+    assert ops.own_f32(whole.double(), "cpu").dtype == torch.float32
