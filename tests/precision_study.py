@@ -5,8 +5,8 @@ Runs the fp32 oracle (oracle/sam_ref.py) with emulated f16 rounding of chosen GE
 weight name matches a policy — and reports the relative error of the mask logits and the mask IoU against the
 un-rounded run.  Split-f16 (hi + lo) operands are emulated as "no rounding" (their error is ~2^-22).
 
-    python tools/precision_study.py --depth 4            # quick
-    python tools/precision_study.py --depth 32           # full ViT-H, ~30 s per policy on 8 cores
+    python tests/precision_study.py --depth 4            # quick
+    python tests/precision_study.py --depth 32           # full ViT-H, ~30 s per policy on 8 cores
 """
 import argparse
 import re
