@@ -88,7 +88,11 @@ __device__ __forceinline__ void init_wave_tile(f32x4 (&acc)[TM][TN], const InkGe
 
 // Each 16-row slab goes through a wave-private LDS patch so that HBM sees whole row segments (16 B per lane,
 // 128 B (f16) / 256 B (f32) contiguous per row); bias / activation / layer-scale are applied on the way in.
-template <int TM, int TN, bool F16O>
+// MODE: -1 = activation / layer scale / late residual decided at run time (the generic kernels);  0, 1, 2 = compile-time
+// "no activation" / GELU / ReLU with no layer scale and no late residual - the ping-pong kernel dispatches on it ONCE per
+// workgroup, so that the 20 activations of a slab form one basic block (the per-group run-time branches cut the GELU
+// into 4-element dependent chains: transcendental latency instead of throughput).
+template <int TM, int TN, bool F16O, int MODE = -1>
 __device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkGemm& p, char* er,
                                                 const int (&rows)[TM], int nw, int lane) {
   constexpr int WNC = TN * 16, EP = WNC * 4 + 16;
@@ -97,7 +101,9 @@ __device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkG
   constexpr int NIT = (16 * CPRW + 63) / 64;       // chunk rounds per slab
   const int fr = lane & 15, fq = lane >> 4;
   const bool wide16 = F16O && (p.ldc % 8 == 0);
-  const bool res_late = p.residual && !residual_preloaded(p);
+  const bool res_late = MODE < 0 && p.residual && !residual_preloaded(p);
+  const int act = MODE < 0 ? p.act : MODE;
+  const bool scaled = MODE < 0 && p.col_scale != nullptr;
   // chunk c = it*64 + lane of a slab: patch row c / CPRW, chunk column c % CPRW (the same for every slab)
   int row_of[NIT], n_of[NIT];
 #pragma unroll
@@ -122,14 +128,14 @@ __device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkG
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       f32x4 v = acc[ti][j];
-      if (p.act == INK_ACT_GELU) {
+      if (act == INK_ACT_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-      } else if (p.act == INK_ACT_RELU) {
+      } else if (act == INK_ACT_RELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
-      if (p.col_scale) {
+      if (scaled) {
         const int n = nw + j * 16 + fq * 4;
         if (n < p.N) v *= *(const f32x4*)(p.col_scale + n);
       }
@@ -390,10 +396,11 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
   int mt, nt;
-  if (group_m > 1) {
-    const int per = group_m * ntn;
-    const int first = (id / per) * group_m;
-    const int gsz = min(ntm - first, group_m);
+  const int gm_abs = group_m < 0 ? -group_m : group_m;
+  if (gm_abs > 1) {
+    const int per = gm_abs * ntn;
+    const int first = (id / per) * gm_abs;
+    const int gsz = min(ntm - first, gm_abs);
     mt = first + (id % per) % gsz;
     nt = (id % per) / gsz;
   } else {
@@ -516,10 +523,22 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
 
   // ---- epilogue: the drained ring is the patch space
   char* er = smem + wave * (16 * EP);
+  // (group_m < 0: A/B switch of tools/gemm_res_ab.py - take the run-time-dispatch epilogue everywhere)
+  const bool plain = group_m > 0 && !p.col_scale && !(p.residual && !residual_preloaded(p));
   if (p.c_f16) {
-    store_wave_tile<TM, TN, true>(acc, p, er, rows, n0 + wn * WNC, lane);
+    if (plain && p.act == INK_ACT_GELU) {          // lin1 of the ViT-H MLP
+      store_wave_tile<TM, TN, true, INK_ACT_GELU>(acc, p, er, rows, n0 + wn * WNC, lane);
+    } else if (plain && p.act == INK_ACT_NONE) {   // qkv
+      store_wave_tile<TM, TN, true, INK_ACT_NONE>(acc, p, er, rows, n0 + wn * WNC, lane);
+    } else {
+      store_wave_tile<TM, TN, true>(acc, p, er, rows, n0 + wn * WNC, lane);
+    }
   } else {
-    store_wave_tile<TM, TN, false>(acc, p, er, rows, n0 + wn * WNC, lane);
+    if (plain && p.act == INK_ACT_NONE) {          // proj, lin2 (residual preloaded into the accumulators)
+      store_wave_tile<TM, TN, false, INK_ACT_NONE>(acc, p, er, rows, n0 + wn * WNC, lane);
+    } else {
+      store_wave_tile<TM, TN, false>(acc, p, er, rows, n0 + wn * WNC, lane);
+    }
   }
   if (ABL & 8) {
     stamp_rt(3);                                    // stores issued (not retired)
@@ -576,7 +595,10 @@ extern "C" int ink_gemm_query_variant(int32_t M, int32_t N, int32_t K) {
 extern "C" int ink_abi_version(void) { return INK_ABI_VERSION; }
 extern "C" int ink_gemm_set_variant(int32_t v) {
   // A process-wide override for the sweep / debugging tools (not thread-safe, not used by the product path).
-  const int base = v >= 100 ? v % 100 : v;
+  // v = gm * 100 + variant; + 10000: the ping-pong kernel takes its run-time-dispatch epilogue (A/B of the
+  // compile-time activation modes, tools/gemm_res_ab.py)
+  const int vv = v >= 10000 ? v - 10000 : v;
+  const int base = vv >= 100 ? vv % 100 : vv;
   bool ok = base == -1 || base == 0 || base == 10 || base == 11 || base == 12 || base == 14 || base == 16 ||
             base == 32 || base == 40 || base == 42 || base == 45 || base == 47 || base == 53;
 #ifdef INK_ABLATION
@@ -602,6 +624,8 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int v = g_variant;           // -1 (default): shape heuristic.  No environment variable reaches this function.
   int gm = 1;
+  bool generic_epilogue = false;
+  if (v >= 10000) { generic_epilogue = true; v -= 10000; }
   if (v >= 100) { gm = v / 100; v = v % 100; }
   if (p.K % 64 != 0) return launch_gemm<128, 128, 32, 2, 2, 2>(p, s);
   if (v < 0) {
@@ -615,7 +639,7 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
   // --ablation`, tools/gemm_stamps.py); the shipped library rejects their numbers in ink_gemm_set_variant.
   switch (v) {
     case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s, gm);       // 16 waves x (64x64), 2 x 64 KB stages
-    case 45: return launch_gemm_pp<4, 5>(p, s, gm);                     // ping-pong 256x320, ring of 4 (144 KB)
+    case 45: return launch_gemm_pp<4, 5>(p, s, generic_epilogue ? -gm : gm);   // ping-pong 256x320, ring of 4 (144 KB)
     case 40: return launch_gemm_pp<4>(p, s, gm);                        // ping-pong 256x256, ring of 4 (128 KB)
     case 42: return launch_gemm_pp<3>(p, s, gm);                        // ... ring of 3 (96 KB)
     case 47: return launch_gemm_pp<3, 5>(p, s, gm);                     // 256x320, ring of 3 (DMA 1 granule ahead)

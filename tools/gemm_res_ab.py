@@ -28,6 +28,19 @@ for (m, n, k, nm) in [(32768, 1280, 1280, "proj"), (32768, 1280, 5120, "lin2"), 
     rows.append(("f32 out, in place x += (product)", ev_time(lambda: ops.gemm(a, w, bias, residual=x, out=x))))
     rows.append(("f32 out, late residual (col_scale=1)", ev_time(lambda: ops.gemm(a, w, bias, residual=x, col_scale=ones, out=o32))))
     rows.append(("f16 out, residual preloaded", ev_time(lambda: ops.gemm(a, w, bias, residual=x, out=o16))))
+    # the same four product calls with the run-time-dispatch epilogue (variant 10000 + 4*100 + 45), interleaved rounds
+    from inklayer_amd import _lib
+    calls = {"qkv-type f16": lambda: ops.gemm(a, w, bias, out=o16), "lin1-type gelu f16": lambda: ops.gemm(a, w, bias, act="gelu", out=o16),
+             "proj-type in place f32": lambda: ops.gemm(a, w, bias, residual=x, out=x)}
+    ab = {}
+    for rnd in range(3):
+        for tag, var in (("compile-time modes", -1), ("run-time dispatch", 10445)):
+            _lib.lib().ink_gemm_set_variant(var)
+            for cn, fn in calls.items():
+                ab.setdefault((cn, tag), []).append(ev_time(fn, iters=10))
+    _lib.lib().ink_gemm_set_variant(-1)
     print(f"{nm} {m}x{n}x{k}")
     for name, us in rows:
         print(f"   {name:42s} {us:8.1f} us  {fl / us / 1e6:6.0f} TF")
+    for (cn, tag), v in sorted(ab.items()):
+        print(f"   A/B {cn:24s} {tag:20s} min {min(v):8.1f} us  median {sorted(v)[1]:8.1f} us")
