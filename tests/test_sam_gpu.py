@@ -193,7 +193,13 @@ def test_pipeline_mixed_sizes_and_empty_detections(dev, small_vith):
     det.cfg.box_threshold = 2.0
     res = pipe.run_batch(imgs)
     assert all(r.masks.shape[0] == 0 and r.boxes_xyxy_norm.shape == (0, 4) for r in res)
+    # ... and through the host-to-host entry (nothing to download), mixed sizes included
+    got = pipe.collect_host(pipe.submit_host(pipe.pinned_like(imgs)))
+    assert [g[3].shape for g in got] == [(0, 512, 512), (0, 600, 800)] and all(g[0].shape == (0, 4) for g in got)
     det.cfg.box_threshold = 0.2
+    got = pipe.collect_host(pipe.submit_host(pipe.pinned_like(imgs), top_n=3))
+    for g, s_ in zip(got, solo):
+        assert np.array_equal(g[3], s_.masks.cpu().numpy()) and g[3].dtype == np.uint8
 
 
 @torch.no_grad()
