@@ -49,7 +49,17 @@ def disk(r: int) -> np.ndarray:
 
 
 def sk_dilate(b: np.ndarray, st: np.ndarray) -> np.ndarray:
-    return ndimage.binary_dilation(b, structure=st, border_value=0)
+    """skimage binary_dilation (outside = background).  A dilation cannot leave the mask's bounding box grown by the
+    structuring element's radius, so only that window is processed (identical result, ~10x less work for object masks)."""
+    ys, xs = np.nonzero(b.any(1))[0], np.nonzero(b.any(0))[0]
+    out = np.zeros(b.shape, dtype=bool)
+    if len(ys) == 0:
+        return out
+    ry, rx = st.shape[0] // 2, st.shape[1] // 2
+    y0, y1 = max(int(ys[0]) - ry, 0), min(int(ys[-1]) + ry + 1, b.shape[0])
+    x0, x1 = max(int(xs[0]) - rx, 0), min(int(xs[-1]) + rx + 1, b.shape[1])
+    out[y0:y1, x0:x1] = ndimage.binary_dilation(b[y0:y1, x0:x1], structure=st, border_value=0)
+    return out
 
 
 def sk_erode(b: np.ndarray, st: np.ndarray) -> np.ndarray:
@@ -128,9 +138,13 @@ def get_binned_frequent(values, bin_width: float = 0.1):
 
 
 def get_mask_depth_score(mask: np.ndarray, points, depth_map: np.ndarray):
-    """depth_sort.py:72-89."""
-    vals = [depth_map[y, x] for (y, x) in points if mask[y, x]]
-    return get_binned_frequent(vals) if vals else float("inf")
+    """depth_sort.py:72-89 (the per-point Python loop as one gather; the binned mode does not depend on the order)."""
+    if len(points) == 0:
+        return float("inf")
+    p = np.asarray(points)
+    inside = np.asarray(mask)[p[:, 0], p[:, 1]] > 0
+    vals = depth_map[p[inside, 0], p[inside, 1]]
+    return get_binned_frequent(vals) if len(vals) else float("inf")
 
 
 def build_containment_graph(bboxes, image_size) -> np.ndarray:
@@ -163,7 +177,7 @@ def compute_major_overlap_matrix(masks, bboxes=None, thr: float = 0.6, dilate_px
     M = [np.asarray(m).astype(np.uint8) for m in masks]
     if dilate_px and dilate_px > 0:
         cross = ndimage.generate_binary_structure(2, 1) if dilate_px == 1 else disk(dilate_px)
-        M = [ndimage.binary_dilation(m > 0, structure=cross, border_value=0).astype(np.uint8) for m in M]
+        M = [sk_dilate(m > 0, cross).astype(np.uint8) for m in M]
     areas = np.array([int(m.sum()) for m in M], dtype=np.int64)
     if bboxes is None:
         bboxes = []
