@@ -72,13 +72,13 @@ def sk_closing(b: np.ndarray, st: np.ndarray) -> np.ndarray:
 
 def png_gray(rgb: np.ndarray) -> np.ndarray:
     """cv2.imread(path, IMREAD_GRAYSCALE) of an 8-bit RGB PNG."""
-    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    r, g, b = (rgb[..., i].astype(np.uint32) for i in range(3))
     return ((r * 9798 + g * 19235 + b * 3735 + 16384) >> 15).astype(np.uint8)
 
 
 def pil_luma(rgb: np.ndarray) -> np.ndarray:
     """PIL Image.convert("L")."""
-    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    r, g, b = (rgb[..., i].astype(np.uint32) for i in range(3))
     return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
 
 
