@@ -53,3 +53,17 @@ def test_kernel_size_rule():
     assert refine_ref.calculate_kernel_size((750, 750)) == 19      # int(18.75) = 18 -> even -> 19
     assert refine_ref.calculate_kernel_size((1024, 1024)) == 25
     assert refine_ref.calculate_kernel_size((512, 800)) == 13      # int(12.8) = 12 -> 13
+
+
+def test_luma_formulas_match_pillow():
+    """PIL Image.convert("L") is the definition of the stroke pixels of the sketch NMS (luma < 250): the oracle's, the
+    host stage's and (through tests/test_refine_gpu.py) the GPU kernel's fixed-point formula must reproduce Pillow."""
+    from PIL import Image
+    from oracle import refine_ref
+    from inklayer_amd import refine_host
+    rs = np.random.RandomState(1)
+    rgb = rs.randint(0, 256, size=(257, 301, 3)).astype(np.uint8)
+    rgb[:8, :8] = [[250, 250, 250]]; rgb[8:16, :8] = [[249, 250, 251]]       # values around the 250 threshold
+    want = np.asarray(Image.fromarray(rgb).convert("L"))
+    assert np.array_equal(refine_ref.pil_luma(rgb), want) and np.array_equal(refine_host.pil_luma(rgb), want)
+    assert np.array_equal(refine_ref.png_gray(rgb), refine_host.png_gray(rgb))
