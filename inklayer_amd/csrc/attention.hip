@@ -24,6 +24,8 @@
 #include "common.h"
 #include "../../include/inklayer_hip.h"
 
+int ink_win4_attn_launch(const InkAttn& p, int n_cus, hipStream_t s);   // attention_win.hip
+
 namespace {
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
@@ -633,6 +635,11 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
     INK_CHECK_ARG(p.rel_aug && p.grid_w > 0 && p.grid_w <= 16 && p.n_k <= p.grid_w * p.grid_w && p.n_k <= 256);
     INK_CHECK_ARG(!p.tok_rows || (p.n_q == p.n_k && p.pad_k && p.pad_v &&
                                   (((uintptr_t)p.pad_k | (uintptr_t)p.pad_v) & 15) == 0));
+    // SAM's own window size (14 x 14 = 196 keys): the one-wave-per-SIMD kernel of attention_win.hip.  Its output
+    // stores go through a 2 GiB buffer descriptor (invalid rows are dropped by the bounds check).
+    if (p.n_k >= 193 && p.n_k <= 208 && p.n_q <= 256 &&
+        (p.tok_rows || (int64_t)p.n_batch * p.n_q * p.ldo * 2 < 0x80000000LL))
+      return ink_win4_attn_launch(p, n_cus, s);
     INK_FA_X(80, 2, 7, true);
   } else if (p.head_dim == 80 && p.bias_mode == 0) {
     INK_FA(80, 0, 4);

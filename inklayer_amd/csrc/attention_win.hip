@@ -1,0 +1,466 @@
+// SAM 14x14-window attention for gfx950 (28 of the 32 ViT-H blocks; SA/modeling/image_encoder.py:206-237 with the
+// window partition of :243-289 folded in through tok_rows).  head_dim 80, 193 <= n_k <= 208 (S = 14: 196), n_q <= 256.
+//
+// One workgroup = FOUR waves, one per SIMD, each with the whole 512-register file, = one (window, head) block at a
+// time, persistent over a contiguous range of blocks (consecutive heads of the same few windows).
+//   * A wave owns TWO 32-query subtiles (A = subtile w, B = subtile w + 4) and runs them half a tile out of phase in
+//     ONE instruction stream:  S_A(t+1) | PV_B(t-1)->(t) | S_B | PV_A | ... so that the softmax of one subtile (VALU:
+//     max, 32 x exp2, convert) is issued in the gaps of the other subtile's MFMAs.  An MFMA 32x32x16 holds vector
+//     issue for 8 of its 32 cycles; each gap takes ~24 cycles of VALU issue, and the order is pinned per gap
+//     (sched_barrier): left to itself hipcc gathers the exps in front of the MFMAs and the phases serialise, which is
+//     what the 2-waves-per-SIMD form of this kernel did (7.4-8.2 us per block for 2.4 us of MFMA).  K' and V fragments
+//     are read from LDS once per wave and used for both subtiles.
+//   * S^T = K' Q'^T with K' = [k | onehot(kh), onehot(kw)], Q' = [q | rel(q,.)/scale]: the decomposed rel-pos bias
+//     rides in the MFMA (two extra 16-wide k-steps); V rows carry a ones-column, so l = sum_k P comes out of the PV
+//     MFMA.  The lane (q = lane & 31) holds 16 keys of ITS query per 32-key half: max / exp are in-lane, one
+//     v_permlane32_swap joins the halves.
+//   * The running max is DEFERRED (cdna_hip_programming.md T13): tile 0 sets m, a later tile rescales only if some
+//     row's max grew by more than 2^12; P is f16 (10-bit mantissa at any magnitude below 65504) and l, O accumulate in
+//     f32, so nothing is lost; the rescale, when taken, happens with every earlier P.V of that subtile complete.
+//   * While block i is computed the operands of block i+1 arrive, all issued by STRAIGHT-LINE code (block indices
+//     clamped to the last block, padded keys by an address select, invalid output rows dropped by the buffer bounds
+//     check instead of a branch), so every wait is a counted vmcnt(N):
+//         top of block i          K and V rows of block i+1 -> 72 registers (handed to LDS between the two barriers of
+//                                 block i+1); token rows of block i+2's window -> 1 register (-> the LDS row table,
+//                                 same place)
+//         after the last S MFMA   Q' fragments of block i+1 -> the (now dead) fragment registers
+//     (LDS-DMA for V was tried: with a DMA in flight hipcc turns every vmcnt wait it inserts into vmcnt(0), which
+//     puts the whole prefetch on the critical path.)
+//   * staging map: thread t < 250 owns chunk t % 10 of keys t / 10 + 25 it (it < 9): its LDS and table addresses
+//     differ by constants.
+#include <type_traits>
+#include "common.h"
+#include "../../include/inklayer_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f16x4 tr_read(const char* p) {
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+  return __builtin_bit_cast(f16x4, v);
+}
+// The softmax arithmetic is issued through VOLATILE asm statements: they keep their place between the sched_barriers of
+// the MFMA gaps.  As plain (pure) operations hipcc's instruction selection hoists them - e.g. all of a tile's second-half
+// exps into the gap that computes the row max - before the machine scheduler ever sees the barriers.
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float d;
+  asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float exp2_at(float s, float c, float neg_m) {      // 2^(s c - m), pinned
+  float t, d;
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(s), "v"(c), "v"(neg_m));
+  asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(t));
+  return d;
+}
+__device__ __forceinline__ uint32_t cvt_pk_at(float a, float b) {              // two f32 -> packed f16 (RNE), pinned
+  uint32_t d;
+  asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x16 mfma(const f16x8& a, const f16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+constexpr int HD = 80, NT = 256, NQKB = 5, NQK = 7, NB = 3, CH = 10;
+constexpr int KROW = 240, VROW = 192, ROWS = 232;     // K' rows: k | one-hot(kh, kw) | pad; V rows: v | ones-column | pad
+constexpr int SKEYS = 25, SIT = 9, STHR = SKEYS * CH;
+constexpr int LDS_BYTES = ROWS * KROW + ROWS * VROW + 256 * 4;
+constexpr float NEG = -1e30f;
+constexpr float THR = 12.0f;          // deferred max: rescale when a row's max grew by more than 2^THR
+
+// One 32-query subtile's softmax state and operands.
+struct Sub {
+  f16x8 qf[NQK];     // Q'^T fragments (B operand): lane (col = q, half hh) holds Q'[q][16 s + 8 hh + j]
+  f32x16 s0, s1;     // S^T of the current tile: keys 0..31 / 32..63 (16 of them per lane)
+  uint32_t pw[16];   // P^T as the PV B operand, packed f16 pairs: 16 keys (4 words) per 16-key step
+  f32x16 o[NB];      // O^T accumulators (d = 0..95; d = 80 / 84 = l)
+  float m, nm;       // running (deferred) max, log2 units, and its negative
+  float mx;          // scratch of the max phase
+  __device__ __forceinline__ f16x8 pfrag(int ks) const {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f16x8, (u32x4){pw[4 * ks], pw[4 * ks + 1], pw[4 * ks + 2], pw[4 * ks + 3]});
+  }
+};
+
+// j-th MFMA of a full-tile S unit (14): k-step j >> 1 on the lower (even j) / upper (odd j) 32 keys
+__device__ __forceinline__ void s_mfma(int j, const f16x8 (&kfa)[NQK], const f16x8 (&kfb)[NQK], Sub& u) {
+  const int s = j >> 1;
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (j & 1) u.s1 = mfma(kfb[s], u.qf[s], s == 0 ? z : u.s1);
+  else u.s0 = mfma(kfa[s], u.qf[s], s == 0 ? z : u.s0);
+}
+// k-step s of the tail tile's S unit (7): only the lower 32 keys exist
+__device__ __forceinline__ void s_mfma_tail(int s, const f16x8 (&kfa)[NQK], Sub& u) {
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  u.s0 = mfma(kfa[s], u.qf[s], s == 0 ? z : u.s0);
+}
+// j-th MFMA of a full-tile PV unit (12): 16-key step j / 3, d-block j % 3
+__device__ __forceinline__ void pv_mfma(int j, const f16x8 (&vf)[12], Sub& u) {
+  u.o[j % 3] = mfma(vf[j], u.pfrag(j / 3), u.o[j % 3]);
+}
+
+// ---- softmax, cut into MFMA-gap sized steps --------------------------------------------------------------------
+// max phase, gaps 0..2: 16 v_max3 over the 32 scores of the lane
+__device__ __forceinline__ void sm_max(int g, Sub& u) {
+  if (g == 0) {
+    u.mx = max3(u.s0[0], u.s0[1], u.s0[2]);
+    u.mx = max3(u.mx, u.s0[3], u.s0[4]);
+    u.mx = max3(u.mx, u.s0[5], u.s0[6]);
+    u.mx = max3(u.mx, u.s0[7], u.s0[8]);
+    u.mx = max3(u.mx, u.s0[9], u.s0[10]);
+    u.mx = max3(u.mx, u.s0[11], u.s0[12]);
+  } else if (g == 1) {
+    u.mx = max3(u.mx, u.s0[13], u.s0[14]);
+    u.mx = max3(u.mx, u.s0[15], u.s1[0]);
+    u.mx = max3(u.mx, u.s1[1], u.s1[2]);
+    u.mx = max3(u.mx, u.s1[3], u.s1[4]);
+    u.mx = max3(u.mx, u.s1[5], u.s1[6]);
+  } else {
+    u.mx = max3(u.mx, u.s1[7], u.s1[8]);
+    u.mx = max3(u.mx, u.s1[9], u.s1[10]);
+    u.mx = max3(u.mx, u.s1[11], u.s1[12]);
+    u.mx = max3(u.mx, u.s1[13], u.s1[14]);
+    u.mx = fmaxf(u.mx, u.s1[15]);
+  }
+}
+// join the half-waves, then either adopt the max (first tile) or check the deferred-max threshold
+template <bool FIRST>
+__device__ __forceinline__ void sm_decide(Sub& u, float c) {
+  // x.hi <-> y.lo: afterwards the lane holds its own value in one of the two and its partner's (lane ^ 32) in the other.
+  // (asm: through __builtin_amdgcn_permlane32_swap this hipcc folds max(r[0], r[1]) to r[0].)
+  float x = u.mx, y = u.mx;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+  const float mc = fmaxf(x, y) * c;
+  if constexpr (FIRST) {
+    u.m = mc;
+    u.nm = -mc;
+  } else {
+    if (__any(mc - u.m > THR)) {          // rare: every earlier P.V of this subtile is complete at this point
+      const float m_new = fmaxf(u.m, mc);
+      const float alpha = __builtin_amdgcn_exp2f(u.m - m_new);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) u.o[i][r2] *= alpha;
+      u.m = m_new;
+      u.nm = -m_new;
+    }
+  }
+}
+// exp step k (0..15): scores 2k, 2k+1 of [s0 | s1] -> p = 2^(s c - m) -> f16 pair of P
+__device__ __forceinline__ void sm_exp(int k, Sub& u, float c) {
+  float a, b;
+  if (k < 8) { a = u.s0[2 * k]; b = u.s0[2 * k + 1]; }
+  else { a = u.s1[2 * k - 16]; b = u.s1[2 * k - 15]; }
+  u.pw[k] = cvt_pk_at(exp2_at(a, c, u.nm), exp2_at(b, c, u.nm));
+}
+// first half of a tile's softmax as 12 gap fillers: 3 max + decide + exp steps 0..7; second half: exp steps 8..15
+template <bool FIRST>
+__device__ __forceinline__ void sm_first(int g, Sub& u, float c) {
+  if (g < 3) sm_max(g, u);
+  else if (g == 3) sm_decide<FIRST>(u, c);
+  else sm_exp(g - 4, u, c);
+}
+__device__ __forceinline__ void sm_second(int g, Sub& u, float c) {
+  if (g < 8) sm_exp(8 + g, u, c);
+}
+// tail tile (keys 192 .. 207 are all a window of n_k <= 208 can hold): 8 scores per lane, keys >= n_k masked
+__device__ __forceinline__ void sm_tail(Sub& u, float c, int n_k, int hh) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int key = 192 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    if (key >= n_k) u.s0[r] = NEG;
+  }
+  u.mx = max3(u.s0[0], u.s0[1], u.s0[2]);
+  u.mx = max3(u.mx, u.s0[3], u.s0[4]);
+  u.mx = max3(u.mx, u.s0[5], u.s0[6]);
+  u.mx = fmaxf(u.mx, u.s0[7]);
+  sm_decide<false>(u, c);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sm_exp(k, u, c);
+}
+
+template <bool TOK>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void win4_attn_kernel(InkAttn p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + ROWS * KROW;
+  int* sT = (int*)(smem + ROWS * KROW + ROWS * VROW);    // token rows of the window being fetched, [256]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31, hh = lane >> 5;
+  const int total = p.n_batch * p.n_heads;
+  int blk = (int)((int64_t)blockIdx.x * total / gridDim.x);
+  const int blk_end = (int)((int64_t)(blockIdx.x + 1) * total / gridDim.x);
+  const int last = blk_end - 1;
+  const int qiA = wave * 32 + lq, qiB = (wave + 4) * 32 + lq;
+  const int qcA = qiA < p.n_q ? qiA : p.n_q - 1, qcB = qiB < p.n_q ? qiB : p.n_q - 1;
+  const int st = tid < STHR ? tid : STHR - 1;          // (the 6 spare threads repeat thread 249's chunks)
+  const int key0 = st / CH, cc = st - key0 * CH;
+  const int tkey = tid < p.n_k ? tid : p.n_k - 1;      // the table entry this thread fetches
+
+  // row (in K/V) of key `tkey` of block blk_'s window, or -1 (window padding)
+  auto fetch_row = [&](int blk_) -> int {
+    const int b_ = blk_ / p.n_heads;
+    if constexpr (TOK) {
+      return p.tok_rows[(int64_t)b_ * p.n_k + tkey];
+    } else {
+      return (p.kv_batch_rows ? p.kv_batch_rows[b_] : b_ * p.n_k) + tkey;
+    }
+  };
+  // row (in Q, and in O with tok_rows) of a query; reads the table of block blk_'s window
+  auto query_row = [&](int blk_, int qc) -> int {
+    if constexpr (TOK) {
+      return sT[qc];                                    // (n_q == n_k with tok_rows)
+    } else {
+      const int b_ = blk_ / p.n_heads;
+      return (p.q_batch_rows ? p.q_batch_rows[b_] : b_ * p.n_q) + qc;
+    }
+  };
+  f16x8 ka[SIT], va[SIT];
+  // K and V rows of block blk_ -> registers; reads the table of blk_'s window
+  auto fetch_kv = [&](int blk_) {
+    const int hc = (blk_ % p.n_heads) * HD + cc * 8;
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+      const int key = key0 + SKEYS * it;                // keys >= n_k: any finite row (they are masked / P = 0)
+      const int r = sT[key < p.n_k ? key : p.n_k - 1];
+      const f16* kp = (const f16*)p.K + (int64_t)r * p.ldk;
+      const f16* vp = (const f16*)p.V + (int64_t)r * p.ldv;
+      if constexpr (TOK) {                              // padded key: qkv(0) = the bias rows
+        kp = r >= 0 ? kp : (const f16*)p.pad_k;
+        vp = r >= 0 ? vp : (const f16*)p.pad_v;
+      }
+      ka[it] = *(const f16x8*)(kp + hc);
+      va[it] = *(const f16x8*)(vp + hc);
+    }
+  };
+  Sub A, B;
+  auto load_q = [&](int blk_, int qrow_, int qc, Sub& u) {
+    const int64_t row = (TOK && qrow_ < 0) ? 0 : qrow_;
+    const f16* Qrow = (const f16*)p.Q + row * p.ldq + (blk_ % p.n_heads) * HD + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < NQKB; ++s) u.qf[s] = *(const f16x8*)(Qrow + 16 * s);
+    const f16* R = (const f16*)p.rel_aug + ((int64_t)blk_ * p.n_q + qc) * 32 + 8 * hh;
+    u.qf[NQKB] = *(const f16x8*)R;
+    u.qf[NQKB + 1] = *(const f16x8*)(R + 16);
+  };
+
+  // constant parts of the LDS image, written once: the one-hot (kh, kw) columns of K' (+ its pad chunk), the pad
+  // columns of V (ones at d = 80 for the lower half-wave, d = 84 for the upper) and zero data for the key slots that
+  // are never staged
+  for (int i = tid; i < ROWS * 2; i += NT) {
+    f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((i & 1) == 0) { z[0] = (f16)1; z[4] = (f16)1; }
+    *(f16x8*)(sV + (i >> 1) * VROW + (CH + (i & 1)) * 16) = z;
+  }
+  for (int i = tid; i < ROWS * 5; i += NT) {
+    const int key = i / 5, c5 = i - key * 5;
+    const int kh = key / p.grid_w, kw = key - kh * p.grid_w + p.grid_w;
+    f16x8 e;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = c5 * 8 + j;
+      e[j] = (c5 < 4 && key < p.n_k && (col == kh || col == kw)) ? (f16)1 : (f16)0;
+    }
+    *(f16x8*)(sK + key * KROW + (CH + c5) * 16) = e;
+  }
+  for (int i = tid; i < (ROWS - SKEYS * SIT) * CH; i += NT) {
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *(f16x8*)(sK + (SKEYS * SIT + i / CH) * KROW + (i % CH) * 16) = z;
+    *(f16x8*)(sV + (SKEYS * SIT + i / CH) * VROW + (i % CH) * 16) = z;
+  }
+  // prologue: table <- window of the first block; its Q, K, V; then the row of the second block's window
+  sT[tid] = fetch_row(blk);
+  __syncthreads();
+  int qrowA = query_row(blk, qcA), qrowB = query_row(blk, qcB);
+  fetch_kv(blk);
+  int rt = fetch_row(blk + 1 < blk_end ? blk + 1 : last);
+  load_q(blk, qrowA, qcA, A);
+  load_q(blk, qrowB, qcB, B);
+
+  const float c = p.scale * 1.44269504088896340736f;
+  const int koff0 = lq * KROW + hh * 16;
+  const int koff1 = (32 + lq) * KROW + hh * 16;
+  const int voff = (4 * hh + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  char* wK = sK + key0 * KROW + cc * 16;               // hand-off destinations of this thread
+  char* wV = sV + key0 * VROW + cc * 16;
+  // invalid output rows (window padding, q >= n_q) get an offset beyond the descriptor's range: the store is dropped
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.O, 0, 0x80000000u, 0x00020000);
+  // (hipcc merges the memory-counter state of the loop entry with the back edge's and waits for the smaller count:
+  // twenty dropped stores here give the entry the block loop's own issue order - rows, Q', stores - so the waits at
+  // the loop top count the stores of the previous block instead of draining them)
+#pragma unroll
+  for (int i = 0; i < 20; ++i)
+    __builtin_amdgcn_raw_buffer_store_b64((i32x2){0, 0}, orsrc, 0x80000000u, 0, 0);
+
+  for (; blk < blk_end; ++blk) {
+    const int b = blk / p.n_heads, h = blk - b * p.n_heads;
+    const bool okA = qiA < p.n_q && (!TOK || qrowA >= 0);    // window padding: nothing to compute, nothing to store
+    const bool okB = qiB < p.n_q && (!TOK || qrowB >= 0);
+    __syncthreads();                                          // every wave has finished reading block blk - 1
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+      *(f16x8*)(wK + it * SKEYS * KROW) = ka[it];
+      *(f16x8*)(wV + it * SKEYS * VROW) = va[it];
+    }
+    sT[tid] = rt;
+    __syncthreads();
+    const int n1 = blk + 1 < blk_end ? blk + 1 : last, n2 = blk + 2 < blk_end ? blk + 2 : last;
+    const int qrow1A = query_row(n1, qcA), qrow1B = query_row(n1, qcB);
+    fetch_kv(n1);
+    rt = fetch_row(n2);
+
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) A.o[i][r] = B.o[i][r] = 0.f;
+    A.m = B.m = NEG;
+    A.nm = B.nm = -NEG;
+    const char* bV = sV;
+    f16x8 kfa[NQK], kfb[NQK], vf[12], vt[NB];
+    auto read_k = [&](int t, int s) {          // K' fragments (A operand) of k-step s of tile t
+      kfa[s] = *(const f16x8*)(sK + t * 64 * KROW + koff0 + s * 32);
+      kfb[s] = *(const f16x8*)(sK + t * 64 * KROW + koff1 + s * 32);
+    };
+    auto read_k_tail = [&](int s) { kfa[s] = *(const f16x8*)(sK + 192 * KROW + koff0 + s * 32); };
+    auto read_v = [&](int t, int j) {          // V^T fragment j = (16-key step j / 3, d-block j % 3) of tile t
+      const char* base = bV + t * 64 * VROW + voff + (16 * (j / 3)) * VROW + (j % 3) * 64;
+      const f16x4 a0 = tr_read(base);
+      const f16x4 a1 = tr_read(base + 8 * VROW);
+      vf[j] = (f16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    };
+    auto read_v_tail = [&](int i) {            // keys 192..207, d-block i
+      const char* base = bV + 192 * VROW + voff + i * 64;
+      const f16x4 a0 = tr_read(base);
+      const f16x4 a1 = tr_read(base + 8 * VROW);
+      vt[i] = (f16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    };
+#define GAP() __builtin_amdgcn_sched_barrier(0)
+
+    {
+      // ---- both subtiles, half a tile out of phase ----
+#pragma unroll
+      for (int s = 0; s < NQK; ++s) read_k(0, s);
+#pragma unroll
+      for (int j = 0; j < 14; ++j) s_mfma(j, kfa, kfb, A);
+      GAP();
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (t == 0) {
+          // pipeline fill: S_B(0)  ||  softmax_A(0), first half; V fragments of tile 0; then the second half alone.
+          // (Every volatile-asm VALU read of an MFMA result below sits at least two MFMAs after the MFMA that wrote it:
+          // hipcc does not pad MFMA -> inline-asm hazards, and CDNA does not interlock them.)
+#pragma unroll
+          for (int g = 0; g < 14; ++g) {
+            s_mfma(g, kfa, kfb, B);
+            if (g < 12) { sm_first<true>(g, A, c); read_v(0, g); }
+            GAP();
+          }
+#pragma unroll
+          for (int g = 0; g < 8; ++g) { sm_second(g, A, c); GAP(); }
+        } else {
+          // PV_B(t-1)  ||  softmax_A(t), first half
+#pragma unroll
+          for (int g = 0; g < 12; ++g) {
+            pv_mfma(g, vf, B);
+            sm_first<false>(g, A, c);
+            GAP();
+          }
+          // S_B(t)  ||  softmax_A(t), second half; V fragments of tile t
+#pragma unroll
+          for (int g = 0; g < 14; ++g) {
+            s_mfma(g, kfa, kfb, B);
+            sm_second(g, A, c);
+            if (g < 12) read_v(t, g);
+            GAP();
+          }
+        }
+        // PV_A(t)  ||  softmax_B(t), first half; K' fragments of tile t + 1 (the tail tile after the third)
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+          pv_mfma(g, vf, A);
+          if (t == 0) sm_first<true>(g, B, c); else sm_first<false>(g, B, c);
+          if (t < 2) {
+            if (g < NQK) read_k(t + 1, g);
+          } else {
+            if (g < NQK) read_k_tail(g);
+          }
+          GAP();
+        }
+        // S_A(t+1)  ||  softmax_B(t), second half   (after the third tile: both tail S units)
+#pragma unroll
+        for (int g = 0; g < 14; ++g) {
+          if (t < 2) s_mfma(g, kfa, kfb, A);
+          else if (g < NQK) s_mfma_tail(g, kfa, A);
+          else s_mfma_tail(g - NQK, kfa, B);
+          sm_second(g, B, c);
+          GAP();
+        }
+      }
+    }
+    // the Q' fragments are dead after the last S MFMA
+    load_q(n1, qrow1A, qcA, A);
+    load_q(n1, qrow1B, qcB, B);
+    {
+      // PV_B(2)  ||  tail softmax of A; tail V fragments
+#pragma unroll
+      for (int g = 0; g < 12; ++g) {
+        pv_mfma(g, vf, B);
+        if (g == 0) sm_tail(A, c, p.n_k, hh);
+        if (g >= 1 && g <= NB) read_v_tail(g - 1);
+        GAP();
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) A.o[i] = mfma(vt[i], A.pfrag(0), A.o[i]);
+      sm_tail(B, c, p.n_k, hh);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) B.o[i] = mfma(vt[i], B.pfrag(0), B.o[i]);
+    }
+#undef GAP
+
+    // O is dense per batch entry unless tok_rows scatters it back to token order
+    auto store_o = [&](const Sub& u, bool ok, int qrow, int qi) {
+      const float inv = 1.0f / u.o[2][8];      // row d = 80 (hh = 0) / 84 (hh = 1) of O^T: sum_k P
+      const uint32_t o_row = TOK ? (uint32_t)qrow : (uint32_t)(b * p.n_q + qi);
+      const uint32_t o_off = ok ? (o_row * (uint32_t)p.ldo + (uint32_t)(h * HD + 4 * hh)) * 2u : 0x80000000u;
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (32 * i + 8 * g < HD) {
+            const f16x4 v = {(f16)(u.o[i][4 * g] * inv), (f16)(u.o[i][4 * g + 1] * inv),
+                             (f16)(u.o[i][4 * g + 2] * inv), (f16)(u.o[i][4 * g + 3] * inv)};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, v), orsrc, o_off, (32 * i + 8 * g) * 2, 0);
+          }
+        }
+    };
+    store_o(A, okA, qrowA, qiA);
+    store_o(B, okB, qrowB, qiB);
+    qrowA = qrow1A;
+    qrowB = qrow1B;
+  }
+}
+
+}  // namespace
+
+// Launcher used by ink_flash_attn (attention.hip) for bias_mode 2 at SAM's window size.
+__attribute__((visibility("hidden"))) int ink_win4_attn_launch(const InkAttn& p, int n_cus, hipStream_t s) {
+  static bool attr = ((void)hipFuncSetAttribute((const void*)win4_attn_kernel<true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES),
+                      (void)hipFuncSetAttribute((const void*)win4_attn_kernel<false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), true);
+  (void)attr;
+  const int bhn = p.n_batch * p.n_heads;
+  const int grid = bhn < n_cus ? bhn : n_cus;            // persistent walk over (window, head) blocks
+  if (p.tok_rows) {
+    hipLaunchKernelGGL(win4_attn_kernel<true>, dim3(grid), dim3(NT), LDS_BYTES, s, p);
+  } else {
+    hipLaunchKernelGGL(win4_attn_kernel<false>, dim3(grid), dim3(NT), LDS_BYTES, s, p);
+  }
+  return ink_launch_status();
+}

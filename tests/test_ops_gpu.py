@@ -200,6 +200,32 @@ def test_flash_attn_sam(dev, S, B, H, relpos):
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("plant", [(70,), (150,), (194,), (70, 150, 194), (3, 194)])
+def test_window_attention_deferred_max_rescale(dev, plant):
+    """The window kernel defers the running max (rescale only when a row's max grows by more than 2^12 between key
+    tiles).  Planted keys whose scores exceed everything before them by far more than that, in the second / third /
+    tail tile and in sequence, drive the rare rescale branch of both subtiles; against float64."""
+    from inklayer_amd import ops
+    S, B, H, hd = 14, 3, 2, 80
+    g = torch.Generator(device="cpu").manual_seed(sum(plant))
+    qkv = torch.randn(B * S * S, 3 * H * hd, generator=g) * 0.7
+    qkv[:, :H * hd] += 0.5                                  # q . ones = 40 + noise
+    x = qkv.view(B, S * S, 3, H, hd)
+    for i, key in enumerate(plant):
+        x[:, key, 1] = 1.5 * (i + 1)                        # k = 1.5, 3, 4.5 x ones: scores +60, +120, +180 (x scale)
+    qkv = qkv.half().to(dev)
+    rph = (torch.randn(2 * S - 1, hd, generator=g) * 0.3).to(dev)
+    rpw = (torch.randn(2 * S - 1, hd, generator=g) * 0.3).to(dev)
+    scale = hd ** -0.5
+    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:2 * H * hd], qkv[:, 2 * H * hd:]
+    r = ops.relpos_bias(q, rph, rpw, S=S, n_batch=B, n_heads=H, head_dim=hd, scale=scale)
+    out = ops.flash_attn(q, k, v, n_batch=B, n_heads=H, head_dim=hd, scale=scale, rel_aug=r, grid_w=S)
+    ref = _ref_sam_attn(qkv, B, H, hd, S, rph, rpw, scale)
+    assert torch.isfinite(out).all()
+    err = (out.double() - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("nq,nk", [(900, 900), (49, 49), (100, 77)])
 def test_flash_attn_hd32(dev, nq, nk):
     from inklayer_amd import ops
