@@ -49,9 +49,13 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
   asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
-__device__ __forceinline__ float exp2_at(float s, float c, float neg_m) {      // 2^(s c - m), pinned
-  float t, d;
+__device__ __forceinline__ float fma_at(float s, float c, float neg_m) {       // s c - m, pinned
+  float t;
   asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(s), "v"(c), "v"(neg_m));
+  return t;
+}
+__device__ __forceinline__ float exp2_at(float t) {                             // 2^t, pinned
+  float d;
   asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(t));
   return d;
 }
@@ -67,9 +71,22 @@ __device__ __forceinline__ f32x16 mfma(const f16x8& a, const f16x8& b, const f32
 constexpr int HD = 80, NT = 256, NQKB = 5, NQK = 7, NB = 3, CH = 10;
 constexpr int KROW = 240, VROW = 192, ROWS = 232;     // K' rows: k | one-hot(kh, kw) | pad; V rows: v | ones-column | pad
 constexpr int SKEYS = 25, SIT = 9, STHR = SKEYS * CH;
-constexpr int LDS_BYTES = ROWS * KROW + ROWS * VROW + 256 * 4;
+constexpr int OROW = 176;                             // output staging rows (160 B of data), one 64-row tile per wave
+constexpr int LDS_BYTES = ROWS * KROW + ROWS * VROW + 256 * 4 + 4 * 64 * OROW + 4 * 64 * 4;
 constexpr float NEG = -1e30f;
 constexpr float THR = 12.0f;          // deferred max: rescale when a row's max grew by more than 2^THR
+
+#ifdef INK_ABLATION
+// measurement build only (tools/win_stamps.py): s_memtime stamps of workgroup 0's waves, [wave][block][16]
+__device__ unsigned long long g_win_stamps[4 * 16 * 16];
+#define STAMP(i)                                                                              \
+  do {                                                                                        \
+    if (blockIdx.x == 0 && lane == 0 && nstamp < 16)                                          \
+      g_win_stamps[(wave * 16 + nstamp) * 16 + (i)] = __builtin_amdgcn_s_memtime();           \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
 
 // One 32-query subtile's softmax state and operands.
 struct Sub {
@@ -78,7 +95,8 @@ struct Sub {
   uint32_t pw[16];   // P^T as the PV B operand, packed f16 pairs: 16 keys (4 words) per 16-key step
   f32x16 o[NB];      // O^T accumulators (d = 0..95; d = 80 / 84 = l)
   float m, nm;       // running (deferred) max, log2 units, and its negative
-  float mx;          // scratch of the max phase
+  float mx, mx2;     // scratch of the max phase (two independent chains)
+  float ea, eb, fa, fb;   // exp pipeline: the fma results of step k and the exps of step k - 1
   __device__ __forceinline__ f16x8 pfrag(int ks) const {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     return __builtin_bit_cast(f16x8, (u32x4){pw[4 * ks], pw[4 * ks + 1], pw[4 * ks + 2], pw[4 * ks + 3]});
@@ -103,27 +121,27 @@ __device__ __forceinline__ void pv_mfma(int j, const f16x8 (&vf)[12], Sub& u) {
 }
 
 // ---- softmax, cut into MFMA-gap sized steps --------------------------------------------------------------------
-// max phase, gaps 0..2: 16 v_max3 over the 32 scores of the lane
+// max phase, gaps 0..2: 16 v_max3 over the 32 scores of the lane, as two independent chains
 __device__ __forceinline__ void sm_max(int g, Sub& u) {
   if (g == 0) {
     u.mx = max3(u.s0[0], u.s0[1], u.s0[2]);
-    u.mx = max3(u.mx, u.s0[3], u.s0[4]);
-    u.mx = max3(u.mx, u.s0[5], u.s0[6]);
-    u.mx = max3(u.mx, u.s0[7], u.s0[8]);
-    u.mx = max3(u.mx, u.s0[9], u.s0[10]);
-    u.mx = max3(u.mx, u.s0[11], u.s0[12]);
+    u.mx2 = max3(u.s0[3], u.s0[4], u.s0[5]);
+    u.mx = max3(u.mx, u.s0[6], u.s0[7]);
+    u.mx2 = max3(u.mx2, u.s0[8], u.s0[9]);
+    u.mx = max3(u.mx, u.s0[10], u.s0[11]);
+    u.mx2 = max3(u.mx2, u.s0[12], u.s0[13]);
   } else if (g == 1) {
-    u.mx = max3(u.mx, u.s0[13], u.s0[14]);
-    u.mx = max3(u.mx, u.s0[15], u.s1[0]);
-    u.mx = max3(u.mx, u.s1[1], u.s1[2]);
-    u.mx = max3(u.mx, u.s1[3], u.s1[4]);
-    u.mx = max3(u.mx, u.s1[5], u.s1[6]);
+    u.mx = max3(u.mx, u.s0[14], u.s0[15]);
+    u.mx2 = max3(u.mx2, u.s1[0], u.s1[1]);
+    u.mx = max3(u.mx, u.s1[2], u.s1[3]);
+    u.mx2 = max3(u.mx2, u.s1[4], u.s1[5]);
+    u.mx = max3(u.mx, u.s1[6], u.s1[7]);
   } else {
-    u.mx = max3(u.mx, u.s1[7], u.s1[8]);
-    u.mx = max3(u.mx, u.s1[9], u.s1[10]);
-    u.mx = max3(u.mx, u.s1[11], u.s1[12]);
-    u.mx = max3(u.mx, u.s1[13], u.s1[14]);
-    u.mx = fmaxf(u.mx, u.s1[15]);
+    u.mx2 = max3(u.mx2, u.s1[8], u.s1[9]);
+    u.mx = max3(u.mx, u.s1[10], u.s1[11]);
+    u.mx2 = max3(u.mx2, u.s1[12], u.s1[13]);
+    u.mx = max3(u.mx, u.s1[14], u.s1[15]);
+    u.mx = fmaxf(u.mx, u.mx2);
   }
 }
 // join the half-waves, then either adopt the max (first tile) or check the deferred-max threshold
@@ -150,14 +168,26 @@ __device__ __forceinline__ void sm_decide(Sub& u, float c) {
     }
   }
 }
-// exp step k (0..15): scores 2k, 2k+1 of [s0 | s1] -> p = 2^(s c - m) -> f16 pair of P
-__device__ __forceinline__ void sm_exp(int k, Sub& u, float c) {
-  float a, b;
-  if (k < 8) { a = u.s0[2 * k]; b = u.s0[2 * k + 1]; }
-  else { a = u.s1[2 * k - 16]; b = u.s1[2 * k - 15]; }
-  u.pw[k] = cvt_pk_at(exp2_at(a, c, u.nm), exp2_at(b, c, u.nm));
+// exp slot i (0..17) of a full tile, a three-stage pipeline over the 16 steps so that no instruction in an MFMA gap
+// waits for its neighbour: fma of step i (scores 2i, 2i+1 of [s0 | s1]: s c - m), exp2 of step i - 1, f16 pair of
+// step i - 2 -> word i - 2 of P
+__device__ __forceinline__ void sm_exp(int i, Sub& u, float c) {
+  float pa = 0.f, pb = 0.f;
+  if (i >= 2 && i < 18) { pa = u.ea; pb = u.eb; }
+  if (i >= 1 && i < 17) {
+    u.ea = exp2_at(u.fa);
+    u.eb = exp2_at(u.fb);
+  }
+  if (i < 16) {
+    float a, b;
+    if (i < 8) { a = u.s0[2 * i]; b = u.s0[2 * i + 1]; }
+    else { a = u.s1[2 * i - 16]; b = u.s1[2 * i - 15]; }
+    u.fa = fma_at(a, c, u.nm);
+    u.fb = fma_at(b, c, u.nm);
+  }
+  if (i >= 2 && i < 18) u.pw[i - 2] = cvt_pk_at(pa, pb);
 }
-// first half of a tile's softmax as 12 gap fillers: 3 max + decide + exp steps 0..7; second half: exp steps 8..15
+// first half of a tile's softmax as 12 gap fillers: 3 max + decide + exp slots 0..7; second half: slots 8..17
 template <bool FIRST>
 __device__ __forceinline__ void sm_first(int g, Sub& u, float c) {
   if (g < 3) sm_max(g, u);
@@ -165,7 +195,7 @@ __device__ __forceinline__ void sm_first(int g, Sub& u, float c) {
   else sm_exp(g - 4, u, c);
 }
 __device__ __forceinline__ void sm_second(int g, Sub& u, float c) {
-  if (g < 8) sm_exp(8 + g, u, c);
+  if (g < 10) sm_exp(8 + g, u, c);
 }
 // tail tile (keys 192 .. 207 are all a window of n_k <= 208 can hold): 8 scores per lane, keys >= n_k masked
 __device__ __forceinline__ void sm_tail(Sub& u, float c, int n_k, int hh) {
@@ -179,8 +209,13 @@ __device__ __forceinline__ void sm_tail(Sub& u, float c, int n_k, int hh) {
   u.mx = max3(u.mx, u.s0[5], u.s0[6]);
   u.mx = fmaxf(u.mx, u.s0[7]);
   sm_decide<false>(u, c);
+  float f[8];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) sm_exp(k, u, c);
+  for (int r = 0; r < 8; ++r) f[r] = fma_at(u.s0[r], c, u.nm);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) f[r] = exp2_at(f[r]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) u.pw[k] = cvt_pk_at(f[2 * k], f[2 * k + 1]);
 }
 
 template <bool TOK>
@@ -189,6 +224,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   char* sK = smem;
   char* sV = smem + ROWS * KROW;
   int* sT = (int*)(smem + ROWS * KROW + ROWS * VROW);    // token rows of the window being fetched, [256]
+  char* sO = smem + ROWS * KROW + ROWS * VROW + 256 * 4;   // per-wave output tiles (wave-private: no barrier)
+  uint32_t* sOoff = (uint32_t*)(sO + 4 * 64 * OROW);       // byte offset in O of each staged row, or 0x80000000
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -223,21 +260,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   };
   f16x8 ka[SIT], va[SIT];
   // K and V rows of block blk_ -> registers; reads the table of blk_'s window
-  auto fetch_kv = [&](int blk_) {
-    const int hc = (blk_ % p.n_heads) * HD + cc * 8;
+  int krow[SIT];
+  auto read_rows = [&]() {                              // all table reads at once: one LDS round trip, not nine
 #pragma unroll
     for (int it = 0; it < SIT; ++it) {
       const int key = key0 + SKEYS * it;                // keys >= n_k: any finite row (they are masked / P = 0)
-      const int r = sT[key < p.n_k ? key : p.n_k - 1];
-      const f16* kp = (const f16*)p.K + (int64_t)r * p.ldk;
-      const f16* vp = (const f16*)p.V + (int64_t)r * p.ldv;
-      if constexpr (TOK) {                              // padded key: qkv(0) = the bias rows
-        kp = r >= 0 ? kp : (const f16*)p.pad_k;
-        vp = r >= 0 ? vp : (const f16*)p.pad_v;
-      }
-      ka[it] = *(const f16x8*)(kp + hc);
-      va[it] = *(const f16x8*)(vp + hc);
+      krow[it] = sT[key < p.n_k ? key : p.n_k - 1];
     }
+  };
+  // load j of the 18 of a block: the K (even j) / V (odd j) chunk of key key0 + 25 (j / 2).  The loads are spread over
+  // the MFMA gaps of the block: issued back to back (4 waves x 19) they overflow the CU's vector-memory queue and every
+  // wave stands still for 4000-6000 cycles until its last load has been accepted.
+  auto fetch_kv_one = [&](int blk_, int j) {
+    const uint32_t hc = (uint32_t)((blk_ % p.n_heads) * HD + cc * 8) * 2u;     // byte offset inside a row
+    const int it = j >> 1, r = krow[it];
+    // padded key (r < 0): qkv(0) = the bias rows.  Both arms of the select are uniform pointers and the row offset is
+    // computed for max(r, 0), so that hipcc emits v_cndmask, not a branch per load
+    const char* base = (j & 1) ? (const char*)p.V : (const char*)p.K;
+    if constexpr (TOK) base = r >= 0 ? base : ((j & 1) ? (const char*)p.pad_v : (const char*)p.pad_k);
+    const uint32_t rp = (uint32_t)(r > 0 ? r : 0);
+    const uint32_t ld2 = (uint32_t)(((j & 1) ? p.ldv : p.ldk) * 2);
+    const f16x8 v = *(const f16x8*)(base + ((uint64_t)rp * ld2 + hc));
+    if (j & 1) va[it] = v; else ka[it] = v;
+  };
+  auto fetch_kv = [&](int blk_) {
+    read_rows();
+#pragma unroll
+    for (int j = 0; j < 2 * SIT; ++j) fetch_kv_one(blk_, j);
   };
   Sub A, B;
   auto load_q = [&](int blk_, int qrow_, int qc, Sub& u) {
@@ -292,14 +341,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   // invalid output rows (window padding, q >= n_q) get an offset beyond the descriptor's range: the store is dropped
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.O, 0, 0x80000000u, 0x00020000);
   // (hipcc merges the memory-counter state of the loop entry with the back edge's and waits for the smaller count:
-  // twenty dropped stores here give the entry the block loop's own issue order - rows, Q', stores - so the waits at
+  // ten dropped stores here give the entry the block loop's own issue order - rows, Q', stores - so the waits at
   // the loop top count the stores of the previous block instead of draining them)
 #pragma unroll
-  for (int i = 0; i < 20; ++i)
+  for (int i = 0; i < 10; ++i)
     __builtin_amdgcn_raw_buffer_store_b64((i32x2){0, 0}, orsrc, 0x80000000u, 0, 0);
 
+  int nstamp = 0;
+  (void)nstamp;
   for (; blk < blk_end; ++blk) {
     const int b = blk / p.n_heads, h = blk - b * p.n_heads;
+    STAMP(0);
     const bool okA = qiA < p.n_q && (!TOK || qrowA >= 0);    // window padding: nothing to compute, nothing to store
     const bool okB = qiB < p.n_q && (!TOK || qrowB >= 0);
     __syncthreads();                                          // every wave has finished reading block blk - 1
@@ -309,11 +361,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       *(f16x8*)(wV + it * SKEYS * VROW) = va[it];
     }
     sT[tid] = rt;
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
     const int n1 = blk + 1 < blk_end ? blk + 1 : last, n2 = blk + 2 < blk_end ? blk + 2 : last;
     const int qrow1A = query_row(n1, qcA), qrow1B = query_row(n1, qcB);
-    fetch_kv(n1);
-    rt = fetch_row(n2);
+    read_rows();
+    STAMP(3);
 
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -349,6 +403,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
       for (int j = 0; j < 14; ++j) s_mfma(j, kfa, kfb, A);
       GAP();
+      STAMP(4);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         if (t == 0) {
@@ -362,7 +417,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             GAP();
           }
 #pragma unroll
-          for (int g = 0; g < 8; ++g) { sm_second(g, A, c); GAP(); }
+          for (int g = 0; g < 10; ++g) {
+            sm_second(g, A, c);
+            if (g >= 6) fetch_kv_one(n1, g - 6);                 // loads 0..3
+            GAP();
+          }
         } else {
           // PV_B(t-1)  ||  softmax_A(t), first half
 #pragma unroll
@@ -377,6 +436,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             s_mfma(g, kfa, kfb, B);
             sm_second(g, A, c);
             if (g < 12) read_v(t, g);
+            if (g >= 10) fetch_kv_one(n1, t == 1 ? g - 2 : g + 4);      // loads 8..11 (t = 1), 14..17 (t = 2)
             GAP();
           }
         }
@@ -399,13 +459,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           else if (g < NQK) s_mfma_tail(g, kfa, A);
           else s_mfma_tail(g - NQK, kfa, B);
           sm_second(g, B, c);
+          if (g >= 10 && t == 0) fetch_kv_one(n1, g - 6);             // loads 4..7
+          if (g >= 12 && t == 1) fetch_kv_one(n1, g);                 // loads 12, 13
+          if (g == 13 && t == 2) rt = fetch_row(n2);
           GAP();
         }
+        STAMP(5 + t);
       }
     }
     // the Q' fragments are dead after the last S MFMA
     load_q(n1, qrow1A, qcA, A);
     load_q(n1, qrow1B, qcB, B);
+    STAMP(8);
     {
       // PV_B(2)  ||  tail softmax of A; tail V fragments
 #pragma unroll
@@ -424,10 +489,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #undef GAP
 
     // O is dense per batch entry unless tok_rows scatters it back to token order
-    auto store_o = [&](const Sub& u, bool ok, int qrow, int qi) {
+    // O^T -> O: the lane holds 4 consecutive d of ITS query per accumulator group, i.e. a row-per-lane store would send
+    // 64 rows x 8 B per instruction (measured: ~175 cycles of issue each, 20 of them per block).  The tile goes through
+    // a wave-private LDS buffer instead and leaves as 160-B row segments, 16 B per lane (10 x 1 KiB per wave).
+    // O is dense per batch entry unless tok_rows scatters it back to token order; invalid rows are dropped.
+    char* myO = sO + wave * 64 * OROW;
+    auto stage_o = [&](const Sub& u, bool ok, int qrow, int qi, int row0) {
       const float inv = 1.0f / u.o[2][8];      // row d = 80 (hh = 0) / 84 (hh = 1) of O^T: sum_k P
-      const uint32_t o_row = TOK ? (uint32_t)qrow : (uint32_t)(b * p.n_q + qi);
-      const uint32_t o_off = ok ? (o_row * (uint32_t)p.ldo + (uint32_t)(h * HD + 4 * hh)) * 2u : 0x80000000u;
+      char* dst = myO + (row0 + lq) * OROW + 8 * hh;
 #pragma unroll
       for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -435,12 +504,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           if (32 * i + 8 * g < HD) {
             const f16x4 v = {(f16)(u.o[i][4 * g] * inv), (f16)(u.o[i][4 * g + 1] * inv),
                              (f16)(u.o[i][4 * g + 2] * inv), (f16)(u.o[i][4 * g + 3] * inv)};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, v), orsrc, o_off, (32 * i + 8 * g) * 2, 0);
+            *(f16x4*)(dst + (32 * i + 8 * g) * 2) = v;
           }
         }
+      const uint32_t o_row = TOK ? (uint32_t)qrow : (uint32_t)(b * p.n_q + qi);
+      if (hh == 0) sOoff[wave * 64 + row0 + lq] = ok ? (o_row * (uint32_t)p.ldo + (uint32_t)(h * HD)) * 2u : 0x80000000u;
     };
-    store_o(A, okA, qrowA, qiA);
-    store_o(B, okB, qrowB, qiB);
+    STAMP(9);
+    stage_o(A, okA, qrowA, qiA, 0);
+    stage_o(B, okB, qrowB, qiB, 32);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int idx = j * 64 + lane, row = idx / CH, ch = idx - row * CH;
+      const f16x8 v = *(const f16x8*)(myO + row * OROW + ch * 16);
+      const uint32_t off = sOoff[wave * 64 + row];
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), orsrc,
+                                             off == 0x80000000u ? off : off + (uint32_t)(ch * 16), 0, 0);
+    }
+    STAMP(10);
+    ++nstamp;
     qrowA = qrow1A;
     qrowB = qrow1B;
   }
@@ -464,3 +547,9 @@ __attribute__((visibility("hidden"))) int ink_win4_attn_launch(const InkAttn& p,
   }
   return ink_launch_status();
 }
+
+#ifdef INK_ABLATION
+extern "C" int ink_win4_read_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_win_stamps), sizeof(g_win_stamps)) == hipSuccess ? INK_OK : INK_ERR_LAUNCH;
+}
+#endif
