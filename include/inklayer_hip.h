@@ -115,7 +115,10 @@ int ink_add_f32(const float* a, const float* b, int64_t n_b, float* out, int64_t
  *              token grid: bias[q,k] = scale*(rel_h[q, k/64] + rel_w[q, k%64]); rel_h/rel_w are
  *              f32 [n_batch*n_heads, n_q, 64] as produced by ink_relpos_bias.
  * bias_mode 2: SAM 14x14 windows: rel_aug f16 [n_batch*n_heads, n_q, 32] from ink_relpos_bias
- *              (cols 0..S-1 = rel_h, S..2S-1 = rel_w); grid_w = S.
+ *              (cols 0..S-1 = rel_h, S..2S-1 = rel_w); grid_w = S <= 16.  At SAM's own size
+ *              (193 <= n_k <= 208, i.e. S = 14) a dedicated kernel runs (csrc/attention_win.hip); it addresses
+ *              rows through 32-bit byte offsets: the O rows it writes must lie within 2 GiB of O, the
+ *              q / k / v rows it gathers within 4 GiB of Q / K / V.
  * bias_mode 3: Swin windows (GD/.../swin_transformer.py:148-167), n_q, n_k <= 64: dense_bias f32
  *              [n_heads, n_q, 64] (relative_position_bias_table gathered by relative_position_index)
  *              + optional dense_mask f32 [n_mask, n_q, 64] (the 0/-100 SW-MSA mask; batch entry b

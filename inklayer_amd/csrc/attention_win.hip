@@ -19,15 +19,22 @@
 //     f32, so nothing is lost; the rescale, when taken, happens with every earlier P.V of that subtile complete.
 //   * While block i is computed the operands of block i+1 arrive, all issued by STRAIGHT-LINE code (block indices
 //     clamped to the last block, padded keys by an address select, invalid output rows dropped by the buffer bounds
-//     check instead of a branch), so every wait is a counted vmcnt(N):
-//         top of block i          K and V rows of block i+1 -> 72 registers (handed to LDS between the two barriers of
-//                                 block i+1); token rows of block i+2's window -> 1 register (-> the LDS row table,
-//                                 same place)
-//         after the last S MFMA   Q' fragments of block i+1 -> the (now dead) fragment registers
-//     (LDS-DMA for V was tried: with a DMA in flight hipcc turns every vmcnt wait it inserts into vmcnt(0), which
-//     puts the whole prefetch on the critical path.)
+//     check instead of a branch), so every wait hipcc inserts is a counted vmcnt(N), and SPREAD over the MFMA gaps of
+//     the block (`vm` below): issued back to back, 4 waves x 19 loads overflow the CU's vector-memory queue and
+//     every wave stands still for 4000-6000 cycles.
+//         K and V rows of block i+1 -> 72 registers (handed to LDS between the two barriers of block i+1); the token
+//         rows of block i+2's window -> 1 register (-> the LDS row table, same place); after the last S MFMA the Q'
+//         fragments of block i+1 -> the (now dead) fragment registers; the O rows of block i-1 leave from a
+//         wave-private LDS tile as 160-B row segments (a row-per-lane store touches 64 cache lines per instruction).
+//     Tried and dropped: LDS-DMA for V (with a DMA in flight hipcc turns every vmcnt wait it inserts into
+//     vmcnt(0)); Q' through the staging tile as coalesced row segments (needs 7 pieces = 28 registers in flight to
+//     cover ~3000-4000 cycles of loaded memory latency; at that pressure hipcc's AGPR-copy rewrite pass crashes,
+//     with 4 rotating registers every piece waits out its latency: 297 us).
 //   * staging map: thread t < 250 owns chunk t % 10 of keys t / 10 + 25 it (it < 9): its LDS and table addresses
 //     differ by constants.
+// Measured (tools/attn_time.py, tools/win_stamps.py): 122 us per launch at B = 8 (336 MB of q,k,v,o: 2.75 TB/s = 34 % of
+// 8 TB/s) against 172 us for the 2-waves-per-SIMD form; per block ~17 000 cycles of which 3 x 2450 are the tiles
+// (52 MFMAs each: 47 cycles per gap, the gap's VALU + LDS + MFMA issue, not the 32 of the MFMA pipe).
 #include <type_traits>
 #include "common.h"
 #include "../../include/inklayer_hip.h"
@@ -67,12 +74,21 @@ __device__ __forceinline__ uint32_t cvt_pk_at(float a, float b) {              /
 __device__ __forceinline__ f32x16 mfma(const f16x8& a, const f16x8& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
+template <int I> using ic = std::integral_constant<int, I>;
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(ic<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 constexpr int HD = 80, NT = 256, NQKB = 5, NQK = 7, NB = 3, CH = 10;
 constexpr int KROW = 240, VROW = 192, ROWS = 232;     // K' rows: k | one-hot(kh, kw) | pad; V rows: v | ones-column | pad
 constexpr int SKEYS = 25, SIT = 9, STHR = SKEYS * CH;
-constexpr int OROW = 176;                             // output staging rows (160 B of data), one 64-row tile per wave
-constexpr int LDS_BYTES = ROWS * KROW + ROWS * VROW + 256 * 4 + 4 * 64 * OROW + 4 * 64 * 4;
+constexpr int XROW = 176;                             // wave-private staging tile: 64 O rows of 160 B
+constexpr int LDS_BYTES = ROWS * KROW + ROWS * VROW + 256 * 4 + 4 * 64 * XROW + 4 * 64 * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr float NEG = -1e30f;
 constexpr float THR = 12.0f;          // deferred max: rescale when a row's max grew by more than 2^THR
 
@@ -224,8 +240,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   char* sK = smem;
   char* sV = smem + ROWS * KROW;
   int* sT = (int*)(smem + ROWS * KROW + ROWS * VROW);    // token rows of the window being fetched, [256]
-  char* sO = smem + ROWS * KROW + ROWS * VROW + 256 * 4;   // per-wave output tiles (wave-private: no barrier)
-  uint32_t* sOoff = (uint32_t*)(sO + 4 * 64 * OROW);       // byte offset in O of each staged row, or 0x80000000
+  char* sX = smem + ROWS * KROW + ROWS * VROW + 256 * 4;   // per-wave staging tiles (wave-private: no barrier)
+  uint32_t* sOoff = (uint32_t*)(sX + 4 * 64 * XROW);       // byte offset in O of each staged row, or 0x80000000
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -299,6 +315,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     u.qf[NQKB + 1] = *(const f16x8*)(R + 16);
   };
 
+  // ---- the wave's staging tile X (64 rows: subtile A's 32 queries, then subtile B's): the O rows of block i are
+  // staged at its end and leave during the first tile of block i+1 as 10 coalesced 1 KiB stores (a row-per-lane store
+  // touches 64 cache lines per instruction: measured ~175 cycles of issue each, 20 of them per block)
+  char* myX = sX + wave * 64 * XROW;
+  uint32_t* myOoff = sOoff + wave * 64;
+  auto x_query = [&](int row) { return row < 32 ? wave * 32 + row : (wave + 4) * 32 + row - 32; };
+  int lane_x = lane;                                    // (made opaque per block: the piece addresses below are cheap
+                                                        // to recompute and must not be hoisted into registers)
+  // one fragment (k-step s2 of 7) of block blk_'s Q'^T for a subtile: row-per-lane, straight into the fragment register
+  auto load_q_piece = [&](int blk_, int qrow_, int qc, Sub& u, int s2) {
+    if (s2 < NQKB) {
+      const int64_t row = (TOK && qrow_ < 0) ? 0 : qrow_;
+      u.qf[s2] = *(const f16x8*)((const f16*)p.Q + row * p.ldq + (blk_ % p.n_heads) * HD + 8 * hh + 16 * s2);
+    } else {
+      u.qf[s2] = *(const f16x8*)((const f16*)p.rel_aug + ((int64_t)blk_ * p.n_q + qc) * 32 + 8 * hh + 16 * (s2 - NQKB));
+    }
+  };
+
   // constant parts of the LDS image, written once: the one-hot (kh, kw) columns of K' (+ its pad chunk), the pad
   // columns of V (ones at d = 80 for the lower half-wave, d = 84 for the upper) and zero data for the key slots that
   // are never staged
@@ -331,6 +365,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   int rt = fetch_row(blk + 1 < blk_end ? blk + 1 : last);
   load_q(blk, qrowA, qcA, A);
   load_q(blk, qrowB, qcB, B);
+  myOoff[lane] = 0x80000000u;                          // (no output rows staged yet: the first block's stores are dropped)
 
   const float c = p.scale * 1.44269504088896340736f;
   const int koff0 = lq * KROW + hh * 16;
@@ -367,6 +402,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int n1 = blk + 1 < blk_end ? blk + 1 : last, n2 = blk + 2 < blk_end ? blk + 2 : last;
     const int qrow1A = query_row(n1, qcA), qrow1B = query_row(n1, qcB);
     read_rows();
+    lane_x = lane;
+    asm volatile("" : "+v"(lane_x));
     STAMP(3);
 
 #pragma unroll
@@ -394,92 +431,126 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       const f16x4 a1 = tr_read(base + 8 * VROW);
       vt[i] = (f16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
     };
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    f16x8 ov[2];
+    uint32_t ooff[2];
+    auto xo_read = [&](int j) {                // piece j (0..9) of the staged O rows of the previous block: LDS -> regs
+      const int idx = j * 64 + lane_x, row = idx / CH, ch = idx - row * CH;
+      ov[j & 1] = *(const f16x8*)(myX + row * XROW + ch * 16);
+      const uint32_t off = myOoff[row];
+      ooff[j & 1] = off == 0x80000000u ? off : off + (uint32_t)(ch * 16);
+    };
+    auto xo_issue = [&](int j) {               // ... -> O (read one slot earlier: no LDS round trip inside a gap)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ov[j & 1]), orsrc, ooff[j & 1], 0, 0);
+    };
+    // The block's vector-memory instructions, spread over its 166 MFMA gaps (G = gap number in the block, a
+    // compile-time constant after unrolling).  Back to back they overflow the CU's vector-memory queue (4 waves x 19
+    // loads: every wave stood still for 4000-6000 cycles); a store whose operand is produced in the same gap stalls the
+    // wave for the producer's latency, hence the one-slot-earlier reads.
+    //   G = 2, 5 .. 29      O rows of the previous block leave (read from the staging tile one slot earlier)
+    //   G = 31, 35 .. 99    the next block's 18 K / V chunks -> registers
+    //   G = 128             the table row of block + 2
+    //   G = 154 .. 165      (after the last S MFMA) its Q' fragments -> the fragment registers, the last two after the tail
+    auto vm = [&](auto G_) {
+      constexpr int G = decltype(G_)::value;
+      if constexpr (G == 0) xo_read(0);
+      if constexpr (G >= 2 && G <= 29 && (G - 2) % 3 == 0) {
+        constexpr int i = (G - 2) / 3;
+        xo_issue(i);
+        if constexpr (i < 9) xo_read(i + 1);
+      }
+      if constexpr (G >= 31 && G <= 99 && (G - 31) % 4 == 0) fetch_kv_one(n1, (G - 31) / 4);
+      if constexpr (G == 128) rt = fetch_row(n2);
+      if constexpr (G >= 154 && G <= 165) {
+        constexpr int k = G - 154;
+        if constexpr (k < NQK) load_q_piece(n1, qrow1A, qcA, A, k); else load_q_piece(n1, qrow1B, qcB, B, k - NQK);
+      }
+    };
 #define GAP() __builtin_amdgcn_sched_barrier(0)
 
     {
       // ---- both subtiles, half a tile out of phase ----
+      // (static_for: the gap numbers must be constants when the arrays are scalarised - with plain unrolled loops the
+      // K / V staging registers ended up in scratch memory)
 #pragma unroll
       for (int s = 0; s < NQK; ++s) read_k(0, s);
 #pragma unroll
       for (int j = 0; j < 14; ++j) s_mfma(j, kfa, kfb, A);
       GAP();
       STAMP(4);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        if (t == 0) {
+      static_for<0, 3>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        if constexpr (t == 0) {
           // pipeline fill: S_B(0)  ||  softmax_A(0), first half; V fragments of tile 0; then the second half alone.
           // (Every volatile-asm VALU read of an MFMA result below sits at least two MFMAs after the MFMA that wrote it:
           // hipcc does not pad MFMA -> inline-asm hazards, and CDNA does not interlock them.)
-#pragma unroll
-          for (int g = 0; g < 14; ++g) {
+          static_for<0, 14>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
             s_mfma(g, kfa, kfb, B);
-            if (g < 12) { sm_first<true>(g, A, c); read_v(0, g); }
+            if constexpr (g < 12) { sm_first<true>(g, A, c); read_v(0, g); }
+            vm(ic<g>{});
             GAP();
-          }
-#pragma unroll
-          for (int g = 0; g < 10; ++g) {
+          });
+          static_for<0, 10>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
             sm_second(g, A, c);
-            if (g >= 6) fetch_kv_one(n1, g - 6);                 // loads 0..3
+            vm(ic<14 + g>{});
             GAP();
-          }
+          });
         } else {
           // PV_B(t-1)  ||  softmax_A(t), first half
-#pragma unroll
-          for (int g = 0; g < 12; ++g) {
+          static_for<0, 12>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
             pv_mfma(g, vf, B);
             sm_first<false>(g, A, c);
+            vm(ic<t * 52 - 2 + g>{});
             GAP();
-          }
+          });
           // S_B(t)  ||  softmax_A(t), second half; V fragments of tile t
-#pragma unroll
-          for (int g = 0; g < 14; ++g) {
+          static_for<0, 14>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
             s_mfma(g, kfa, kfb, B);
             sm_second(g, A, c);
-            if (g < 12) read_v(t, g);
-            if (g >= 10) fetch_kv_one(n1, t == 1 ? g - 2 : g + 4);      // loads 8..11 (t = 1), 14..17 (t = 2)
+            if constexpr (g < 12) read_v(t, g);
+            vm(ic<t * 52 + 10 + g>{});
             GAP();
-          }
+          });
         }
         // PV_A(t)  ||  softmax_B(t), first half; K' fragments of tile t + 1 (the tail tile after the third)
-#pragma unroll
-        for (int g = 0; g < 12; ++g) {
+        static_for<0, 12>([&](auto g_) {
+          constexpr int g = decltype(g_)::value;
           pv_mfma(g, vf, A);
-          if (t == 0) sm_first<true>(g, B, c); else sm_first<false>(g, B, c);
-          if (t < 2) {
-            if (g < NQK) read_k(t + 1, g);
-          } else {
-            if (g < NQK) read_k_tail(g);
+          sm_first<t == 0>(g, B, c);
+          if constexpr (g < NQK) {
+            if constexpr (t < 2) read_k(t + 1, g); else read_k_tail(g);
           }
+          vm(ic<t * 52 + 24 + g>{});
           GAP();
-        }
+        });
         // S_A(t+1)  ||  softmax_B(t), second half   (after the third tile: both tail S units)
-#pragma unroll
-        for (int g = 0; g < 14; ++g) {
-          if (t < 2) s_mfma(g, kfa, kfb, A);
-          else if (g < NQK) s_mfma_tail(g, kfa, A);
+        static_for<0, 14>([&](auto g_) {
+          constexpr int g = decltype(g_)::value;
+          if constexpr (t < 2) s_mfma(g, kfa, kfb, A);
+          else if constexpr (g < NQK) s_mfma_tail(g, kfa, A);
           else s_mfma_tail(g - NQK, kfa, B);
           sm_second(g, B, c);
-          if (g >= 10 && t == 0) fetch_kv_one(n1, g - 6);             // loads 4..7
-          if (g >= 12 && t == 1) fetch_kv_one(n1, g);                 // loads 12, 13
-          if (g == 13 && t == 2) rt = fetch_row(n2);
+          vm(ic<t * 52 + 36 + g>{});
           GAP();
-        }
+        });
         STAMP(5 + t);
-      }
+      });
     }
-    // the Q' fragments are dead after the last S MFMA
-    load_q(n1, qrow1A, qcA, A);
-    load_q(n1, qrow1B, qcB, B);
     STAMP(8);
     {
       // PV_B(2)  ||  tail softmax of A; tail V fragments
-#pragma unroll
-      for (int g = 0; g < 12; ++g) {
+      static_for<0, 12>([&](auto g_) {
+        constexpr int g = decltype(g_)::value;
         pv_mfma(g, vf, B);
-        if (g == 0) sm_tail(A, c, p.n_k, hh);
-        if (g >= 1 && g <= NB) read_v_tail(g - 1);
+        if constexpr (g == 0) sm_tail(A, c, p.n_k, hh);
+        if constexpr (g >= 1 && g <= NB) read_v_tail(g - 1);
+        vm(ic<154 + g>{});
         GAP();
-      }
+      });
 #pragma unroll
       for (int i = 0; i < NB; ++i) A.o[i] = mfma(vt[i], A.pfrag(0), A.o[i]);
       sm_tail(B, c, p.n_k, hh);
@@ -488,15 +559,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 #undef GAP
 
-    // O is dense per batch entry unless tok_rows scatters it back to token order
-    // O^T -> O: the lane holds 4 consecutive d of ITS query per accumulator group, i.e. a row-per-lane store would send
-    // 64 rows x 8 B per instruction (measured: ~175 cycles of issue each, 20 of them per block).  The tile goes through
-    // a wave-private LDS buffer instead and leaves as 160-B row segments, 16 B per lane (10 x 1 KiB per wave).
-    // O is dense per batch entry unless tok_rows scatters it back to token order; invalid rows are dropped.
-    char* myO = sO + wave * 64 * OROW;
+    // O^T -> staging tile (after the Q' fragments have been read out of it): the lane holds 4 consecutive d of ITS
+    // query per accumulator group; the rows leave during the next block's first tile.  O is dense per batch entry
+    // unless tok_rows scatters it back to token order; invalid rows get an offset the buffer bounds check drops.
     auto stage_o = [&](const Sub& u, bool ok, int qrow, int qi, int row0) {
       const float inv = 1.0f / u.o[2][8];      // row d = 80 (hh = 0) / 84 (hh = 1) of O^T: sum_k P
-      char* dst = myO + (row0 + lq) * OROW + 8 * hh;
+      char* dst = myX + (row0 + lq) * XROW + 8 * hh;
 #pragma unroll
       for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -508,24 +576,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           }
         }
       const uint32_t o_row = TOK ? (uint32_t)qrow : (uint32_t)(b * p.n_q + qi);
-      if (hh == 0) sOoff[wave * 64 + row0 + lq] = ok ? (o_row * (uint32_t)p.ldo + (uint32_t)(h * HD)) * 2u : 0x80000000u;
+      if (hh == 0) myOoff[row0 + lq] = ok ? (o_row * (uint32_t)p.ldo + (uint32_t)(h * HD)) * 2u : 0x80000000u;
     };
     STAMP(9);
+    load_q_piece(n1, qrow1B, qcB, B, 5);
+    load_q_piece(n1, qrow1B, qcB, B, 6);
     stage_o(A, okA, qrowA, qiA, 0);
     stage_o(B, okB, qrowB, qiB, 32);
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-      const int idx = j * 64 + lane, row = idx / CH, ch = idx - row * CH;
-      const f16x8 v = *(const f16x8*)(myO + row * OROW + ch * 16);
-      const uint32_t off = sOoff[wave * 64 + row];
-      typedef int i32x4 __attribute__((ext_vector_type(4)));
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), orsrc,
-                                             off == 0x80000000u ? off : off + (uint32_t)(ch * 16), 0, 0);
-    }
     STAMP(10);
     ++nstamp;
     qrowA = qrow1A;
     qrowB = qrow1B;
+  }
+  // the last block's output rows
+  typedef int i32x4b __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    const int idx = j * 64 + lane, row = idx / CH, ch = idx - row * CH;
+    const f16x8 v = *(const f16x8*)(myX + row * XROW + ch * 16);
+    const uint32_t off = myOoff[row];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4b, v), orsrc,
+                                           off == 0x80000000u ? off : off + (uint32_t)(ch * 16), 0, 0);
   }
 }
 

@@ -239,6 +239,8 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: in
         for t in (pad_k, pad_v):
             assert t is not None and t.dtype == F16 and t.is_contiguous() and t.numel() == n_heads * head_dim
         assert out.dtype == F16 and out.stride(1) == 1
+        # (the window kernel addresses O, and the gathered q / k / v rows, through 32-bit byte offsets)
+        assert out.shape[0] * out.stride(0) * 2 < 2 ** 31 and q.shape[0] * q.stride(0) * 2 < 2 ** 32
     else:
         if out is None:
             out = torch.empty((n_batch * n_q, n_heads * head_dim), device=q.device, dtype=F16)
