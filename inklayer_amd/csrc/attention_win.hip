@@ -111,6 +111,7 @@ struct Sub {
   uint32_t pw[16];   // P^T as the PV B operand, packed f16 pairs: 16 keys (4 words) per 16-key step
   f32x16 o[NB];      // O^T accumulators (d = 0..95; d = 80 / 84 = l)
   float m, nm;       // running (deferred) max, log2 units, and its negative
+  bool ok;           // this lane's query exists (not window padding): only such lanes vote for a rescale
   float mx, mx2;     // scratch of the max phase (two independent chains)
   float ea, eb, fa, fb;   // exp pipeline: the fma results of step k and the exps of step k - 1
   __device__ __forceinline__ f16x8 pfrag(int ks) const {
@@ -172,7 +173,9 @@ __device__ __forceinline__ void sm_decide(Sub& u, float c) {
     u.m = mc;
     u.nm = -mc;
   } else {
-    if (__any(mc - u.m > THR)) {          // rare: every earlier P.V of this subtile is complete at this point
+    // rare: every earlier P.V of this subtile is complete at this point.  Padding lanes compute on a stand-in row
+    // (row 0 of Q) and must not vote, or a window's rounding would depend on what else is in the batch.
+    if (__any(u.ok && mc - u.m > THR)) {
       const float m_new = fmaxf(u.m, mc);
       const float alpha = __builtin_amdgcn_exp2f(u.m - m_new);
 #pragma unroll
@@ -411,6 +414,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
       for (int r = 0; r < 16; ++r) A.o[i][r] = B.o[i][r] = 0.f;
     A.m = B.m = NEG;
+    A.ok = okA;
+    B.ok = okB;
     A.nm = B.nm = -NEG;
     const char* bV = sV;
     f16x8 kfa[NQK], kfb[NQK], vf[12], vt[NB];
