@@ -37,6 +37,11 @@ def set_attn_trace(lst) -> None:
     _ATTN_TRACE = lst
 
 
+def tracing_off() -> bool:
+    """No per-launch event bracketing requested (a captured graph would bypass it)."""
+    return _GEMM_TRACE is None and _ATTN_TRACE is None
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 

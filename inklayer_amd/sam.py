@@ -31,6 +31,7 @@ import numpy as np
 import torch
 
 from . import ops
+from ._lru import LRU
 
 F16, F32 = torch.float16, torch.float32
 
@@ -256,6 +257,8 @@ class SamEngine:
         self.nwin = nwin
         Mw = nwin * nwin * ws * ws               # 4900 rows per image after padding
         self.Mw = Mw
+        self._enc_graphs = LRU(self.graph_cache_size)
+        self._enc_seen: Dict[int, int] = {}
         # window gather/scatter map (window_partition / window_unpartition, image_encoder.py:243-289)
         r = torch.arange(B * Mw)
         b, rr = r // Mw, r % Mw
@@ -295,6 +298,48 @@ class SamEngine:
                              chan_reverse, self.buf_patches[b * T:(b + 1) * T], split=self.precise_tail)
             ops.gemm(self.buf_patches[b * T:(b + 1) * T], w["pe.ws" if self.precise_tail else "pe.w"], w["pe.b"],
                      residual=w["pos"], out=x[b * T:(b + 1) * T])
+        if upto is None and self.graph_blocks and ops.tracing_off():
+            return self._blocks_graphed(B)
+        return self._blocks(B, upto)
+
+    # ------------------------------------------------------------------ HIP graph of the 32 blocks + neck
+    # The blocks and the neck only touch engine-owned buffers of fixed shape per batch size: ~370 launches that can be
+    # replayed as one graph.  Measured at batch 8 (tools/host_time.py, tools/bench_ab.py): the host needs 2.4 ms to
+    # issue them eagerly (6.4 us per launch through ctypes) and 0.2 ms to replay the graph, against 53 ms of GPU work -
+    # the step is not host-bound, and same-box A/B runs of the whole pipeline agree within the pool's noise (76.8-77.7 ms
+    # either way).  So the graph is OFF by default and kept for hosts with slow cores (one attribute to flip).  A batch
+    # size is captured the second time it is seen (a capture costs three forwards and pins a private pool for the
+    # neck's intermediates); the result is cloned out of that pool.
+    graph_blocks = False
+    graph_cache_size = 2
+
+    def _blocks_graphed(self, B: int) -> torch.Tensor:
+        g = self._enc_graphs.get(B)
+        if g is None:
+            self._enc_seen[B] = self._enc_seen.get(B, 0) + 1
+            if self._enc_seen[B] < 2:
+                return self._blocks(B, None)
+            x0 = self.x[:B * self.T].clone()              # the capture's warm-ups run the blocks in place
+            cur = torch.cuda.current_stream(self.dev)
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):                 # warm-up off the capture: lazy attribute calls, plans
+                self._blocks(B, None)
+                self.x[:B * self.T].copy_(x0)
+            cur.wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._blocks(B, None)
+            self.x[:B * self.T].copy_(x0)
+            g = (graph, out)
+            self._enc_graphs.put(B, g)
+        g[0].replay()
+        return g[1].clone()                               # the static output is overwritten by the next replay
+
+    def _blocks(self, B: int, upto: Optional[int]) -> torch.Tensor:
+        cfg, w, T, D = self.cfg, self.w, self.T, self.cfg.embed_dim
+        H, Mw = cfg.num_heads, self.Mw
+        x = self.x[:B * T]
         nblk = cfg.depth if upto is None else upto
         for i in range(nblk):
             k = f"b{i}."

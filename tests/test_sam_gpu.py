@@ -81,6 +81,28 @@ def test_encoder_batch2_equals_batch1(dev, small_vith):
 
 
 @torch.no_grad()
+def test_encoder_graph_replay_equals_eager(dev, small_vith):
+    """The blocks + neck are replayed as one HIP graph from the second sighting of a batch size on: eager, capturing
+    and replaying calls must agree bit for bit, also after another batch size evicted nothing / was captured too."""
+    sd, oc, eng = small_vith
+    a = torch.from_numpy(_sketch(0)).to(dev)
+    b = torch.from_numpy(_sketch(1, 900, 1024)).to(dev)
+    saved = eng.graph_blocks
+    try:
+        eng.graph_blocks = False
+        ref_a, ref_ab = eng.encode([a]).clone(), eng.encode([a, b]).clone()
+        eng.graph_blocks = True
+        eng._enc_graphs = type(eng._enc_graphs)(eng.graph_cache_size)
+        eng._enc_seen.clear()
+        for _ in range(3):                                   # eager, capture, replay
+            assert torch.equal(eng.encode([a]), ref_a)
+            assert torch.equal(eng.encode([a, b]), ref_ab)
+        assert len(eng._enc_graphs) == 2
+    finally:
+        eng.graph_blocks = saved
+
+
+@torch.no_grad()
 def test_decoder_matches_oracle(dev, small_vith):
     from oracle import sam_ref
     sd, oc, eng = small_vith
