@@ -25,6 +25,7 @@
 #include "../../include/inklayer_hip.h"
 
 int ink_win4_attn_launch(const InkAttn& p, int n_cus, hipStream_t s);   // attention_win.hip
+int ink_glob4_attn_launch(const InkAttn& p, hipStream_t s);              // attention_glob.hip
 
 namespace {
 
@@ -630,6 +631,8 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
 #define INK_FA(HD, MODE, NW) INK_FA_X(HD, MODE, NW, false)
   if (p.head_dim == 80 && p.bias_mode == 1) {
     INK_CHECK_ARG(p.rel_h && p.rel_w && p.grid_w == 64 && p.n_k % 64 == 0);
+    // SAM's own shape (64 x 64 tokens): the one-wave-per-SIMD kernel of attention_glob.hip
+    if (p.n_q % 256 == 0 && p.n_k % 128 == 0 && p.n_k >= 256 && p.n_k <= 4096) return ink_glob4_attn_launch(p, s);
     INK_FA(80, 1, 8);
   } else if (p.head_dim == 80 && p.bias_mode == 2) {
     INK_CHECK_ARG(p.rel_aug && p.grid_w > 0 && p.grid_w <= 16 && p.n_k <= p.grid_w * p.grid_w && p.n_k <= 256);

@@ -226,6 +226,31 @@ def test_window_attention_deferred_max_rescale(dev, plant):
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("plant", [(70,), (1500,), (4090,), (70, 1500, 4090), (3, 130)])
+def test_global_attention_deferred_max_rescale(dev, plant):
+    """Same as the window test for the global kernel (64 x 64 tokens, 64 key tiles): planted keys far above everything
+    before them, in the second tile, in the middle, in the last tile and in sequence."""
+    from inklayer_amd import ops
+    S, B, H, hd = 64, 1, 2, 80
+    g = torch.Generator(device="cpu").manual_seed(sum(plant))
+    qkv = torch.randn(B * S * S, 3 * H * hd, generator=g) * 0.7
+    qkv[:, :H * hd] += 0.5
+    x = qkv.view(B, S * S, 3, H, hd)
+    for i, key in enumerate(plant):
+        x[:, key, 1] = 1.5 * (i + 1)
+    qkv = qkv.half().to(dev)
+    rph = (torch.randn(2 * S - 1, hd, generator=g) * 0.3).to(dev)
+    rpw = (torch.randn(2 * S - 1, hd, generator=g) * 0.3).to(dev)
+    scale = hd ** -0.5
+    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:2 * H * hd], qkv[:, 2 * H * hd:]
+    rh, rw = ops.relpos_bias(q, rph, rpw, S=S, n_batch=B, n_heads=H, head_dim=hd, scale=scale)
+    out = ops.flash_attn(q, k, v, n_batch=B, n_heads=H, head_dim=hd, scale=scale, rel_h=rh, rel_w=rw, grid_w=S)
+    ref = _ref_sam_attn(qkv, B, H, hd, S, rph, rpw, scale)
+    assert torch.isfinite(out).all()
+    err = (out.double() - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("nq,nk", [(900, 900), (49, 49), (100, 77)])
 def test_flash_attn_hd32(dev, nq, nk):
     from inklayer_amd import ops
