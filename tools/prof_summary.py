@@ -6,8 +6,8 @@ def bucket(name):
     if "gemm_f16_nt_pp<4, 5" in name: return "gemm_pp320"
     if "gemm_f16_nt<256, 256, 64, 4, 4, 2" in name: return "gemm256"
     if "gemm_f16_nt" in name: return "gemm_other"
-    if "flash_attn_kernel<80, 1" in name: return "attn_global"
-    if "flash_attn_kernel<80, 2" in name: return "attn_window"
+    if "flash_attn_kernel<80, 1" in name or "glob4_attn_kernel" in name: return "attn_global"
+    if "flash_attn_kernel<80, 2" in name or "win4_attn_kernel" in name: return "attn_window"
     if "flash_attn" in name or "attn_few" in name: return "attn_other"
     if "layernorm" in name or "ln_merge" in name or "groupnorm" in name: return "norm"
     return "other"
