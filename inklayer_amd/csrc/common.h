@@ -39,17 +39,19 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // erf-form GELU, as torch.nn.GELU() default.  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e.
-// f32-rounding level for GELU's use) with v_rcp / v_exp: branch-free, ~12 VALU ops instead of libm's erff.
+// f32-rounding level for GELU's use) with v_rcp / v_exp: branch-free, 12 VALU + 2 transcendental ops instead of
+// libm's erff.  With e = 1 - erf(|x| / sqrt 2):  gelu(x) = max(x, 0) - (|x| / 2) e  for either sign of x, and the
+// exponent's log2(e) is folded into the argument: u = |x| sqrt(log2(e) / 2), e = poly(t) t 2^(-u u),
+// t = 1 / (1 + p |x| / sqrt 2) = 1 / (1 + (p / sqrt(log2 e)) u).
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float u = fabsf(x) * 0.84932180028801904272f;                  // sqrt(log2(e) / 2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.27273748087922250f, u, 1.0f));   // 0.3275911 / sqrt(log2 e)
   float pl = fmaf(1.061405429f, t, -1.453152027f);
   pl = fmaf(pl, t, 1.421413741f);
   pl = fmaf(pl, t, -0.284496736f);
   pl = fmaf(pl, t, 0.254829592f);
-  const float e = pl * t * __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);   // 1 - erf(|z|)
-  const float erf_abs = 1.0f - e;
-  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+  const float e = pl * t * __builtin_amdgcn_exp2f(-(u * u));           // 1 - erf(|x| / sqrt 2)
+  return fmaf(-0.5f * fabsf(x), e, fmaxf(x, 0.0f));
 }
 
 // bijective XCD-aware block remap: blocks b and b+8 share an XCD (round-robin

@@ -251,6 +251,32 @@ def test_global_attention_deferred_max_rescale(dev, plant):
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("nq,nk", [(512, 1024), (256, 256), (768, 4096), (320, 1024), (512, 192)])
+def test_global_attention_rectangular(dev, nq, nk):
+    """bias_mode 1 with given rel_h / rel_w tables on rectangular problems: n_q % 256 == 0 and n_k % 128 == 0 take the
+    one-wave-per-SIMD kernel (2 .. 64 key tiles, 1 .. 3 query tiles per head), the others the streamed one."""
+    from inklayer_amd import ops
+    B, H, hd = 2, 2, 80
+    g = torch.Generator(device="cpu").manual_seed(nq + nk)
+    q = (torch.randn(B * nq, H * hd, generator=g) * 1.2).half().to(dev)
+    k = (torch.randn(B * nk, H * hd, generator=g) * 1.2).half().to(dev)
+    v = torch.randn(B * nk, H * hd, generator=g).half().to(dev)
+    rel_h = (torch.randn(B * H, nq, 64, generator=g) * 3).to(dev)
+    rel_w = (torch.randn(B * H, nq, 64, generator=g) * 3).to(dev)
+    scale = hd ** -0.5
+    out = ops.flash_attn(q, k, v, n_batch=B, n_heads=H, head_dim=hd, scale=scale, n_q=nq, n_k=nk,
+                         rel_h=rel_h, rel_w=rel_w, grid_w=64)
+    qd = q.double().view(B, nq, H, hd).transpose(1, 2)
+    kd = k.double().view(B, nk, H, hd).transpose(1, 2)
+    vd = v.double().view(B, nk, H, hd).transpose(1, 2)
+    kk = torch.arange(nk, device=dev)
+    bias = rel_h.double().view(B, H, nq, 64)[..., kk // 64] + rel_w.double().view(B, H, nq, 64)[..., kk % 64]
+    ref = (((qd @ kd.transpose(-1, -2)) + bias) * scale).softmax(-1) @ vd
+    ref = ref.transpose(1, 2).reshape(B * nq, H * hd)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("nq,nk", [(900, 900), (49, 49), (100, 77)])
 def test_flash_attn_hd32(dev, nq, nk):
     from inklayer_amd import ops
