@@ -69,6 +69,9 @@ class _NullCtx:
 
 
 class InkLayerPipeline:
+    det_priority = 0
+    seg_priority = 0
+
     def __init__(self, detector: gd.GDinoEngine, segmentor: sm.SamEngine, overlap: bool = True):
         self.det, self.seg = detector, segmentor
         self.dev = detector.dev
@@ -77,8 +80,9 @@ class InkLayerPipeline:
         # streams mostly time-slice rather than co-reside; what the second stream buys is the gaps (kernel tails,
         # the host round trip for the boxes): ~8 ms of the detector's ~20 ms per batch of 8.
         self.overlap = overlap
-        self.s_det = torch.cuda.Stream(device=self.dev) if overlap else None
-        self.s_seg = torch.cuda.Stream(device=self.dev) if overlap else None
+        # stream priorities (class attributes so that tools can A/B them): see DESIGN.md §7
+        self.s_det = torch.cuda.Stream(device=self.dev, priority=self.det_priority) if overlap else None
+        self.s_seg = torch.cuda.Stream(device=self.dev, priority=self.seg_priority) if overlap else None
         # host <-> device traffic of the host-to-host entry points rides its own streams, one per direction (on ONE
         # stream the upload of batch i+1 would queue behind the mask download of batch i and put both on the
         # critical path): the upload of batch i+1 and the download of batch i run under the neighbouring batch's
