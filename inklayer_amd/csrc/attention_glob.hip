@@ -244,11 +244,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     loff[it] = v ? 64 * KROW + row * VROW + cc * 16 : row * KROW + cc * 16;
   }
   f16x8 stg[2][5];
-  auto g_load = [&](int tile, auto SET, auto IT) {
+  // the five chunk addresses walk from tile to tile by a stride instead of being recomputed (the address arithmetic
+  // of a load sits in an MFMA gap like everything else; measured neutral against recomputing them, same-box A/B)
+  const char* gp[5];
+#pragma unroll
+  for (int it = 0; it < 5; ++it) gp[it] = (isv[it] ? Vg : Kg) + goff[it];
+  const int64_t kstride = (int64_t)64 * p.ldk * 2, vstride = (int64_t)64 * p.ldv * 2;
+  auto g_load = [&](int tile, auto SET, auto IT) {           // tiles are requested in order 0, 1, 2, 3, ...
     constexpr int set = decltype(SET)::value, it = decltype(IT)::value;
-    const int tl = tile < ntiles ? tile : ntiles - 1;
-    const char* base = isv[it] ? Vg + (int64_t)tl * 64 * p.ldv * 2 : Kg + (int64_t)tl * 64 * p.ldk * 2;
-    stg[set][it] = *(const f16x8*)(base + goff[it]);
+    stg[set][it] = *(const f16x8*)gp[it];
+    const int64_t step = tile + 1 < ntiles ? (isv[it] ? vstride : kstride) : 0;     // (the last tile is re-read)
+    gp[it] += step;
   };
   auto l_write = [&](int buf, auto SET, auto IT) {
     constexpr int set = decltype(SET)::value, it = decltype(IT)::value;
