@@ -26,6 +26,11 @@
 // tile, two v_exp per MFMA gap) ADD to the skeleton instead of hiding in it.  The guide's rule is one transcendental
 // per gap; 64 exps per tile do not fit 44 gaps, so the kernel is bound by VALU/transcendental issue, not by the MFMA
 // pipe (1408 cycles per tile).  Removing the next tile's global loads (timing experiment) gives -500 cycles.
+// Further timing experiments (results wrong on purpose, stamps only): v_exp replaced by v_add -240 cycles per tile; no
+// fma and no cvt -340; no max phase -300.  No single class of filler is the cost - each gap that carries ANY VALU work
+// runs ~50 cycles longer than a bare MFMA gap; with none the tile takes 2050 (46 per MFMA, the LDS / load skeleton).
+// I.e. in this instruction stream the wave's own VALU does not hide under its MFMAs the way the guide's single-wave
+// measurements suggest; why (operand-port conflicts of 512-register waves? the volatile-asm pinning?) is open.
 #include <type_traits>
 #include "common.h"
 #include "../../include/inklayer_hip.h"
