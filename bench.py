@@ -183,8 +183,8 @@ def attention_summary(trace, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="sketches per GPU per step")
     ap.add_argument("--boxes", type=int, default=16, help="boxes per sketch (top-n by score)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
