@@ -113,20 +113,38 @@ def unnormalize_bboxes(bboxes, h: int, w: int) -> List[List[int]]:
 def sketch_to_01binary(sketch_bgr: np.ndarray) -> np.ndarray:
     """refinement/utils.py:3-9 on a cv2.imread colour image: channel 0 (blue) <= max/2 -> 1.0."""
     s = sketch_bgr if sketch_bgr.ndim == 3 else sketch_bgr[:, :, None]
-    return (1.0 * ~(s > s.max() / 2))[:, :, 0]
+    return 1.0 * ~(s[:, :, 0] > s.max() / 2)              # (the threshold is the maximum over ALL channels)
 
 
 def sparse_sketch_sample(binary_edge_map: np.ndarray) -> List[Tuple[int, int]]:
-    """depth_sort.py:49-68: greedy thinning of the stroke pixels with a KD-tree ball query (radius 1 % of the height)."""
-    from scipy.spatial import KDTree
-    radius = binary_edge_map.shape[0] * 0.01
-    pts = np.column_stack(np.where(binary_edge_map > 0))
-    tree = KDTree(pts)
-    sampled, remaining = [], set(range(len(pts)))
-    while remaining:
-        cur = next(iter(remaining))
-        sampled.append(tuple(pts[cur]))
-        remaining.difference_update(tree.query_ball_point(pts[cur], radius))
+    """depth_sort.py:49-68: greedy thinning of the stroke pixels - take the first remaining pixel (row-major), drop every
+    stroke pixel within 1 % of the height of it, repeat.  The reference walks a Python set of point indices
+    (`next(iter(remaining))`: for a set built from range(n) that is the smallest remaining index) and asks a KD-tree for
+    the ball; here the points sit in an index image and a ball is a disk-masked window of it - the same samples in the
+    same order (pinned against the literal form on the reference's sketches, tests/test_refiner_cpu.py), ~6x faster."""
+    H, W = binary_edge_map.shape
+    radius = H * 0.01
+    ys, xs = np.where(binary_edge_map > 0)
+    n = len(ys)
+    if n == 0:
+        return []
+    r = int(np.floor(radius))
+    idx = np.full((H + 2 * r, W + 2 * r), -1, dtype=np.int64)
+    idx[ys + r, xs + r] = np.arange(n)
+    dy, dx = np.mgrid[-r:r + 1, -r:r + 1]
+    disk = (dy * dy + dx * dx) <= radius * radius          # (query_ball_point is inclusive)
+    alive = np.ones(n, dtype=bool)
+    sampled, cur = [], 0
+    while True:
+        rest = alive[cur:]
+        k = int(rest.argmax()) if len(rest) else 0
+        if len(rest) == 0 or not rest[k]:
+            break
+        cur += k
+        y, x = ys[cur], xs[cur]
+        sampled.append((y, x))
+        win = idx[y:y + 2 * r + 1, x:x + 2 * r + 1]
+        alive[win[disk & (win >= 0)]] = False
     return sampled
 
 
@@ -230,11 +248,12 @@ def sort_sketch_masks(masks, bboxes, sketch_rgb: np.ndarray, depth_map: np.ndarr
 # disjoint parsing  (refiner.py:21-129)
 # ---------------------------------------------------------------------------------------------------------------
 def clean_delicate_mask(mask: np.ndarray, isolation_threshold: int = 1) -> np.ndarray:
-    """refiner.py:21-33: drop pixels with at most one 8-neighbour."""
-    k = np.ones((3, 3), dtype=int)
-    k[1, 1] = 0
+    """refiner.py:21-33: drop pixels with at most one 8-neighbour (the reference convolves with a 3x3 ring; the
+    neighbour count is the sum of the eight shifted images)."""
+    p = np.pad((np.asarray(mask) > 0).astype(np.uint8), 1)
+    cnt = (p[:-2, :-2] + p[:-2, 1:-1] + p[:-2, 2:] + p[1:-1, :-2] + p[1:-1, 2:] + p[2:, :-2] + p[2:, 1:-1] + p[2:, 2:])
     out = mask.copy()
-    out[ndimage.convolve(mask.astype(int), k, mode="constant", cval=0) <= isolation_threshold] = False
+    out[cnt <= isolation_threshold] = False
     return out
 
 

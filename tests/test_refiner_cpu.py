@@ -108,3 +108,39 @@ def test_depth_ordering_on_synthetic_depth():
     m = np.zeros((9, 9), bool); m[4, 1:8] = True; m[0, 0] = True
     c = R.clean_delicate_mask(m)
     assert not c[0, 0] and not c[4, 1] and not c[4, 7] and c[4, 2:7].all()
+
+
+
+def _sparse_sketch_sample_literal(binary_edge_map):
+    """depth_sort.py:49-68 as written there (a Python set of point indices + a KD-tree ball query per sample)."""
+    from scipy.spatial import KDTree
+    radius = binary_edge_map.shape[0] * 0.01
+    pts = np.column_stack(np.where(binary_edge_map > 0))
+    tree = KDTree(pts)
+    sampled, remaining = [], set(range(len(pts)))
+    while remaining:
+        cur = next(iter(remaining))
+        sampled.append(tuple(pts[cur]))
+        remaining.difference_update(tree.query_ball_point(pts[cur], radius))
+    return sampled
+
+
+@pytest.mark.parametrize("name", ["bunny_cook_sketch", "animal_hike_sketch", "office_sketch", "clock_lamp_plant",
+                                  "fscoco_animals", "mario_bunny", "Clipasso_brushpen_0249"])
+def test_fast_host_forms_equal_the_literal_ones(name):
+    """refine_host's index-image thinning and shifted-sum neighbour count against the reference's literal forms (set +
+    KD-tree; scipy convolve with the 3x3 ring) on the reference's own sketches and cleaned masks: identical output."""
+    from scipy import ndimage
+    from inklayer_amd import refine_host as R
+    z = np.load(str(Path(__file__).resolve().parent / "golden" / f"refine_{name}.npz"))
+    rgb = z["input"]
+    binary = R.sketch_to_01binary(rgb[..., ::-1])
+    assert R.sparse_sketch_sample(binary) == _sparse_sketch_sample_literal(binary)
+    H, W = [int(v) for v in z["hw"]]
+    cleaned = np.unpackbits(z["masks_cleaned"], axis=-1)[..., :W].astype(bool)
+    k = np.ones((3, 3), dtype=int)
+    k[1, 1] = 0
+    for m in cleaned[z["masks_cleaned_present"]][:6]:
+        want = m.copy()
+        want[ndimage.convolve(m.astype(int), k, mode="constant", cval=0) <= 1] = False
+        assert np.array_equal(R.clean_delicate_mask(m), want)
