@@ -48,22 +48,52 @@ def disk(r: int) -> np.ndarray:
     return (X ** 2 + Y ** 2) <= r ** 2
 
 
+def _window(b: np.ndarray, st: np.ndarray):
+    """Bounding box of the mask grown by the structuring element's radius, clipped to the image (None if empty)."""
+    ys, xs = np.nonzero(b.any(1))[0], np.nonzero(b.any(0))[0]
+    if len(ys) == 0:
+        return None
+    ry, rx = st.shape[0] // 2, st.shape[1] // 2
+    return (max(int(ys[0]) - ry, 0), min(int(ys[-1]) + ry + 1, b.shape[0]),
+            max(int(xs[0]) - rx, 0), min(int(xs[-1]) + rx + 1, b.shape[1]), ry, rx)
+
+
 def sk_dilate(b: np.ndarray, st: np.ndarray) -> np.ndarray:
     """skimage binary_dilation (outside = background).  A dilation cannot leave the mask's bounding box grown by the
-    structuring element's radius, so only that window is processed (identical result, ~10x less work for object masks)."""
-    ys, xs = np.nonzero(b.any(1))[0], np.nonzero(b.any(0))[0]
+    structuring element's radius, so only that window is processed, as the OR of the window shifted by every offset
+    of the (small, symmetric) structuring element - identical result (tests/test_refiner_cpu.py), ~20x less work
+    than scipy's generic routine on the full image."""
     out = np.zeros(b.shape, dtype=bool)
-    if len(ys) == 0:
+    w = _window(b, st)
+    if w is None:
         return out
-    ry, rx = st.shape[0] // 2, st.shape[1] // 2
-    y0, y1 = max(int(ys[0]) - ry, 0), min(int(ys[-1]) + ry + 1, b.shape[0])
-    x0, x1 = max(int(xs[0]) - rx, 0), min(int(xs[-1]) + rx + 1, b.shape[1])
-    out[y0:y1, x0:x1] = ndimage.binary_dilation(b[y0:y1, x0:x1], structure=st, border_value=0)
+    y0, y1, x0, x1, ry, rx = w
+    p = np.pad(b[y0:y1, x0:x1], ((ry, ry), (rx, rx)), constant_values=False)
+    h, wd = y1 - y0, x1 - x0
+    acc = np.zeros((h, wd), dtype=bool)
+    for dy, dx in zip(*np.nonzero(st)):
+        acc |= p[dy:dy + h, dx:dx + wd]
+    out[y0:y1, x0:x1] = acc
     return out
 
 
 def sk_erode(b: np.ndarray, st: np.ndarray) -> np.ndarray:
-    return ndimage.binary_erosion(b, structure=st, border_value=1)
+    """skimage binary_erosion (outside the image = foreground).  An erosion stays inside the mask's bounding box and
+    only looks one structuring-element radius beyond it: that window is processed, as the AND of its shifts (where the
+    window ends inside the image its margin is background, so the foreground padding only acts where the window
+    touches the image edge)."""
+    out = np.zeros(b.shape, dtype=bool)
+    w = _window(b, st)
+    if w is None:
+        return out
+    y0, y1, x0, x1, ry, rx = w
+    p = np.pad(b[y0:y1, x0:x1], ((ry, ry), (rx, rx)), constant_values=True)
+    h, wd = y1 - y0, x1 - x0
+    acc = np.ones((h, wd), dtype=bool)
+    for dy, dx in zip(*np.nonzero(st)):
+        acc &= p[dy:dy + h, dx:dx + wd]
+    out[y0:y1, x0:x1] = acc
+    return out
 
 
 def sk_closing(b: np.ndarray, st: np.ndarray) -> np.ndarray:
@@ -96,10 +126,11 @@ def compute_bbox_iou(box1, box2) -> float:
 
 def compute_mask_bbox(mask: np.ndarray):
     """refinement/utils.py:34-39."""
-    ys, xs = np.where(mask)
+    m = np.asarray(mask) != 0
+    ys, xs = np.nonzero(m.any(1))[0], np.nonzero(m.any(0))[0]      # (row / column projections instead of np.where)
     if len(ys) == 0:
         return None
-    return [np.min(xs), np.min(ys), np.max(xs), np.max(ys)]
+    return [xs[0], ys[0], xs[-1], ys[-1]]
 
 
 def unnormalize_bboxes(bboxes, h: int, w: int) -> List[List[int]]:
