@@ -144,3 +144,22 @@ def test_fast_host_forms_equal_the_literal_ones(name):
         want = m.copy()
         want[ndimage.convolve(m.astype(int), k, mode="constant", cval=0) <= 1] = False
         assert np.array_equal(R.clean_delicate_mask(m), want)
+
+
+def test_window_morphology_equals_scipy():
+    """sk_dilate / sk_erode (shifts of the mask's window) against scipy's generic routines with skimage's border
+    conventions, on random masks that touch the image border and on every structuring element the stage uses."""
+    from scipy import ndimage
+    from inklayer_amd import refine_host as R
+    rs = np.random.RandomState(1)
+    sts = (R.disk(1), R.disk(2), R.disk(3), ndimage.generate_binary_structure(2, 1), np.ones((3, 3), bool))
+    for t in range(150):
+        H, W = rs.randint(12, 90), rs.randint(12, 90)
+        m = np.zeros((H, W), bool)
+        for _ in range(rs.randint(0, 4)):
+            y0, x0 = rs.randint(0, H), rs.randint(0, W)
+            y1, x1 = min(H, y0 + rs.randint(1, 40)), min(W, x0 + rs.randint(1, 40))
+            m[y0:y1, x0:x1] = rs.rand(y1 - y0, x1 - x0) > 0.2
+        for st in sts:
+            assert np.array_equal(R.sk_erode(m, st), ndimage.binary_erosion(m, structure=st, border_value=1) & m.any())
+            assert np.array_equal(R.sk_dilate(m, st), ndimage.binary_dilation(m, structure=st, border_value=0))
