@@ -90,7 +90,17 @@ constexpr int XROW = 176;                             // wave-private staging ti
 constexpr int LDS_BYTES = ROWS * KROW + ROWS * VROW + 256 * 4 + 4 * 64 * XROW + 4 * 64 * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr float NEG = -1e30f;
-constexpr float THR = 12.0f;          // deferred max: rescale when a row's max grew by more than 2^THR
+constexpr float THR = 12.0f;
+// schedule knobs of `vm` (tools/win_variants.sh builds alternatives for same-box A/B runs)
+#ifndef INK_WIN_KV_STEP
+#define INK_WIN_KV_STEP 4
+#endif
+#ifndef INK_WIN_ST_STEP
+#define INK_WIN_ST_STEP 3
+#endif
+#ifndef INK_WIN_QA_EARLY
+#define INK_WIN_QA_EARLY 0
+#endif          // deferred max: rescale when a row's max grew by more than 2^THR
 
 #ifdef INK_ABLATION
 // measurement build only (tools/win_stamps.py): s_memtime stamps of workgroup 0's waves, [wave][block][16]
@@ -459,14 +469,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     auto vm = [&](auto G_) {
       constexpr int G = decltype(G_)::value;
       if constexpr (G == 0) xo_read(0);
-      if constexpr (G >= 2 && G <= 29 && (G - 2) % 3 == 0) {
-        constexpr int i = (G - 2) / 3;
+      constexpr int ST = INK_WIN_ST_STEP, KS = INK_WIN_KV_STEP, KV0 = 2 + ST * 9 + 2;
+      static_assert(KV0 + KS * 17 < 140, "the K / V loads end before the table row load");
+      if constexpr (G >= 2 && G <= 2 + ST * 9 && (G - 2) % ST == 0) {
+        constexpr int i = (G - 2) / ST;
         xo_issue(i);
         if constexpr (i < 9) xo_read(i + 1);
       }
-      if constexpr (G >= 31 && G <= 99 && (G - 31) % 4 == 0) fetch_kv_one(n1, (G - 31) / 4);
-      if constexpr (G == 128) rt = fetch_row(n2);
-      if constexpr (G >= 154 && G <= 165) {
+      if constexpr (G >= KV0 && G <= KV0 + KS * 17 && (G - KV0) % KS == 0) fetch_kv_one(n1, (G - KV0) / KS);
+      if constexpr (G == 140) rt = fetch_row(n2);
+      if constexpr (INK_WIN_QA_EARLY) {       // A's fragments are dead after its tail S unit (G 140..146)
+        if constexpr (G >= 147 && G <= 153) load_q_piece(n1, qrow1A, qcA, A, G - 147);
+        if constexpr (G >= 154 && G <= 160) load_q_piece(n1, qrow1B, qcB, B, G - 154);
+      } else if constexpr (G >= 154 && G <= 165) {
         constexpr int k = G - 154;
         if constexpr (k < NQK) load_q_piece(n1, qrow1A, qcA, A, k); else load_q_piece(n1, qrow1B, qcB, B, k - NQK);
       }
@@ -584,8 +599,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       if (hh == 0) myOoff[row0 + lq] = ok ? (o_row * (uint32_t)p.ldo + (uint32_t)(h * HD)) * 2u : 0x80000000u;
     };
     STAMP(9);
-    load_q_piece(n1, qrow1B, qcB, B, 5);
-    load_q_piece(n1, qrow1B, qcB, B, 6);
+    if constexpr (!INK_WIN_QA_EARLY) {
+      load_q_piece(n1, qrow1B, qcB, B, 5);
+      load_q_piece(n1, qrow1B, qcB, B, 6);
+    }
     stage_o(A, okA, qrowA, qiA, 0);
     stage_o(B, okB, qrowB, qiB, 32);
     STAMP(10);
