@@ -17,15 +17,19 @@ weights_path = get_model_path("inklayer_gdino.pth")
 model = None
 
 
-def load_model(config_path=gdino_config_path, checkpoint_path=weights_path, device="cuda"):
-    """groundingdino.util.inference.load_model (GD/util/inference.py:29-36) for the HIP engine."""
+def load_model(config_path=None, checkpoint_path=None, device="cuda"):
+    """groundingdino.util.inference.load_model (GD/util/inference.py:29-36) for the HIP engine.  The defaults are the
+    module attributes `gdino_config_path` / `weights_path`, read at CALL time."""
     import torch
+    checkpoint_path = weights_path if checkpoint_path is None else checkpoint_path
     from inklayer_amd import gdino, text_branch, weights_init
     cfg = gdino.GDinoConfig()
     if os.environ.get("INKLAYER_RANDOM_WEIGHTS") == "1":      # no checkpoints exist offline
         sd = weights_init.random_gdino_state_dict(cfg, device)
         text = weights_init.random_text_features(cfg, device)
     else:
+        if not os.path.exists(checkpoint_path):
+            raise FileNotFoundError(f"Checkpoint not found at {checkpoint_path}")
         ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
         sd = gdino.clean_state_dict(ckpt["model"] if "model" in ckpt else ckpt)   # GD/util/inference.py:33-34
         text = text_branch.encode_caption_from_checkpoint(sd, gdino.DEFAULT_TOKEN_IDS)

@@ -101,8 +101,9 @@ def test_runner_plugins_full_depth_against_oracle(dev, tmp_path, monkeypatch):
     e = dist[np.arange(n), match]
     se = np.abs(np.asarray(dino_out["scores"]) - all_sc[match])
     print("plugin boxes vs matched oracle queries: err", e.tolist(), "score err", se.tolist())
-    assert len(set(match.tolist())) == n and np.median(e) < 3e-3 and e.max() < 0.1
-    assert np.median(se) < 5e-3 and se.max() < 0.1
+    # bounds = 10x the errors this test logs on the MI355X (boxes 1.4e-3, scores 3e-4)
+    assert len(set(match.tolist())) == n and np.median(e) < 3e-3 and e.max() < 1.4e-2
+    assert np.median(se) < 5e-3 and se.max() < 3e-3
     clear = 0.03
     assert set(np.nonzero(all_sc > thr + clear)[0].tolist()) <= set(match.tolist())
     assert (all_sc[match] > thr - clear).all()
@@ -147,12 +148,29 @@ def test_runner_plugins_full_depth_against_oracle(dev, tmp_path, monkeypatch):
     assert got_depth.shape == (H, W) and rel < 1e-2
     kept = want_final["kept_indices"]
     boxes_px = refine_host.unnormalize_bboxes(want_final["bboxes"], H, W)
-    dis, sboxes, _ = refine_host.parse_masks_to_disjoint_masks([want_clean[i] for i in kept], boxes_px, np.asarray(pil), ref_depth)
-    fin = refine_host.improve_sam_masks(np.asarray(pil), dis, sboxes)
-    assert len(list((out_dir / "masks_disjoint").iterdir())) == len(dis) and len(list((out_dir / "masks_final").iterdir())) == len(fin)
-    same = all(np.array_equal(np.asarray(Image.open(out_dir / "masks_final" / f"mask_{i}.png")) > 0, np.asarray(m) > 0)
-               for i, m in enumerate(fin))
-    print("masks_final identical to the host stage on the oracle's depth:", same)
+
+    def host_stage(depth):
+        dis, sboxes, _ = refine_host.parse_masks_to_disjoint_masks([want_clean[i] for i in kept], boxes_px, np.asarray(pil), depth)
+        return dis, refine_host.improve_sam_masks(np.asarray(pil), dis, sboxes)
+
+    def tree_equals(sub, want):
+        files = sorted((out_dir / sub).iterdir(), key=lambda p_: int(p_.stem.split("_")[1]))
+        return len(files) == len(want) and all(
+            np.array_equal(np.asarray(Image.open(f)) > 0, np.asarray(m) > 0) for f, m in zip(files, want))
+
+    # the runner's trees are EXACTLY the refinement stage applied to the oracle-cleaned masks under the depth map the
+    # runner computed ...
+    dis, fin = host_stage(got_depth)
+    assert tree_equals("masks_disjoint", dis), "masks_disjoint/ differs from the refinement stage on the runner's depth map"
+    assert tree_equals("masks_final", fin), "masks_final/ differs from the refinement stage on the runner's depth map"
+    # ... and the same under the ORACLE's depth map whenever the two depth maps order the masks identically (the depth
+    # scores are histogram modes of a map that agrees to 1e-2: an order swap between near-equal scores is legitimate)
+    order_of = lambda depth: refine_host.sort_sketch_masks([want_clean[i] for i in kept], boxes_px, np.asarray(pil), depth)[0]
+    o_got, o_ref = [int(i) for i in order_of(got_depth)], [int(i) for i in order_of(ref_depth)]
+    print("depth order under the runner's / the oracle's depth map:", o_got, o_ref)
+    if o_got == o_ref:
+        dis_r, fin_r = host_stage(ref_depth)
+        assert tree_equals("masks_disjoint", dis_r) and tree_equals("masks_final", fin_r)
     DS._engine = None
     DET.model = None
     SEG._engine = None
