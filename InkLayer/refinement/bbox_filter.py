@@ -27,7 +27,7 @@ def process_json_with_sketch_NMS(sketch_path: str, masks_dir: str, input_data: D
     sketch = np.asarray(Image.open(sketch_path).convert("RGB"))
     if cleaned_masks is None:
         cleaned_masks = _cleaned_stack(masks_dir, len(input_data["bboxes"]), sketch.shape[:2])
-    on_gpu = torch.from_numpy(np.ascontiguousarray(cleaned_masks)).to("cuda")
+    on_gpu = cleaned_masks if torch.is_tensor(cleaned_masks) else torch.from_numpy(np.ascontiguousarray(cleaned_masks)).to("cuda")
     return refine.process_json_with_sketch_nms(sketch, input_data, on_gpu, iou_threshold)
 
 

@@ -1,8 +1,10 @@
-"""Depth model plugin (reference: InkLayer/refinement/depth_sort.py:35-46), MI355X engine underneath.
+"""Depth model plugin + mask ordering (reference: InkLayer/refinement/depth_sort.py:35-46, 244-295), MI355X underneath.
 
-`get_depth_map(sketch_path) -> HxW float32 numpy` = DepthAnythingV2("vitb").infer_image(cv2.imread(sketch_path)).
-The model is a lazily created singleton kept resident in HBM (the reference builds it at import).  The mask-ordering
-logic (sort_sketch_masks and helpers, depth_sort.py:49-295) is host code, as in the reference: inklayer_amd/refine_host.py."""
+`get_depth_map(sketch_path) -> HxW float32 numpy` = DepthAnythingV2("vitb").infer_image(cv2.imread(sketch_path)); the
+model is a lazily created singleton kept resident in HBM (the reference builds it at import).
+`sort_sketch_masks(masks, bboxes, sketch_path, depth_sketch=None) -> (order deepest first, depth scores, containment)`:
+the pixel work (stroke / mask intersections, dilated overlaps, depth samples) runs on the GPU
+(inklayer_amd/refine_stage.py), the ordering of a few dozen numbers on the host."""
 import os
 
 import numpy as np
@@ -19,7 +21,6 @@ def _get_engine():
     if _engine is None:
         from inklayer_amd import depth
         if os.environ.get("INKLAYER_RANDOM_WEIGHTS") == "1":          # no checkpoints exist offline
-            import torch
             cfg = depth.DepthConfig()
             from inklayer_amd import weights_init
             _engine = depth.DepthEngine(weights_init.random_depth_state_dict(cfg, "cuda"), cfg, "cuda")
@@ -31,17 +32,24 @@ def _get_engine():
     return _engine
 
 
-def get_depth_map(sketch_path):
+def get_depth_map_device(sketch_path):
+    """The depth map as a float32 [H, W] tensor that stays on the GPU (what the refinement stage consumes)."""
     rgb = np.asarray(Image.open(sketch_path).convert("RGB"))
     bgr = np.ascontiguousarray(rgb[..., ::-1])                        # cv2.imread returns BGR
-    return _get_engine().infer_image(bgr).cpu().numpy()
+    return _get_engine().infer_image(bgr)
+
+
+def get_depth_map(sketch_path):
+    return get_depth_map_device(sketch_path).cpu().numpy()
 
 
 def sort_sketch_masks(masks, bboxes, sketch_path, depth_sketch=None):
-    """depth_sort.py:244-295: -> (order deepest first, depth scores, containment graph)."""
-    from inklayer_amd import refine_host
+    import torch
+    from inklayer_amd import refine_stage
     assert os.path.exists(sketch_path), f"Sketch path {sketch_path} does not exist."
-    if depth_sketch is None:
-        depth_sketch = get_depth_map(sketch_path)
     rgb = np.asarray(Image.open(sketch_path).convert("RGB"))
-    return refine_host.sort_sketch_masks([np.asarray(m) > 0 for m in masks], bboxes, rgb, depth_sketch)
+    depth = get_depth_map_device(sketch_path) if depth_sketch is None else \
+        torch.from_numpy(np.ascontiguousarray(depth_sketch, np.float32)).to("cuda")
+    stack = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(m) > 0 for m in masks]).astype(np.uint8))).to("cuda") \
+        if len(masks) else torch.zeros((0,) + rgb.shape[:2], dtype=torch.uint8, device="cuda")
+    return refine_stage.refine_masks(stack, [list(b) for b in bboxes], rgb, depth.contiguous(), only_order=True)

@@ -18,16 +18,26 @@ def calculate_kernel_size(image_shape, factor=0.025):
     return (k, k)
 
 
-def clean_masks_in_memory(masks):
+def clean_masks_on_device(masks):
     """A sequence of equally sized HxW masks (bool, or uint8 where > 127 is foreground) -> cleaned uint8 [n, H, W]
-    (0 / 255), computed on the GPU."""
+    (0 / 255) as a CUDA tensor that STAYS in HBM (the sketch NMS and the refinement stage consume it there); None for
+    an empty sequence.  The components pass' overflow flag is read once here and raises."""
     import torch
-    from inklayer_amd import refine
+    from inklayer_amd import _lib, refine
     if len(masks) == 0:
-        return np.zeros((0, 0, 0), np.uint8)
+        return None
     stack = np.stack([np.asarray(m) for m in masks])
     stack = stack.astype(np.uint8) * 255 if stack.dtype == np.bool_ else stack.astype(np.uint8)
-    return refine.clean_masks(torch.from_numpy(np.ascontiguousarray(stack)).to("cuda")).cpu().numpy()
+    out = refine.clean_masks(torch.from_numpy(np.ascontiguousarray(stack)).to("cuda"))
+    if int(out._ink_overflow_flag.item()) != 0:
+        raise _lib.InkLayerHipError("ink_mask_cleanup: a row has more runs than the closing bound allows (workspace overflow)")
+    return out
+
+
+def clean_masks_in_memory(masks):
+    """-> cleaned uint8 [n, H, W] (0 / 255) numpy, computed on the GPU."""
+    dev = clean_masks_on_device(masks)
+    return np.zeros((0, 0, 0), np.uint8) if dev is None else dev.cpu().numpy()
 
 
 def clean_up_mask(binary_mask):
@@ -48,6 +58,8 @@ def run_clean_masks_on_sketch_dir(sketch_dir, masks=None, cleaned=None):
             count = len(glob.glob(os.path.join(src, "mask_*.png")))
             masks = [np.asarray(Image.open(os.path.join(src, f"mask_{i}.png")).convert("L")) for i in range(count)]
         cleaned = clean_masks_in_memory(masks)
+    if hasattr(cleaned, "cpu"):
+        cleaned = cleaned.cpu().numpy()
     for i, m in enumerate(cleaned):
         Image.fromarray(m, "L").save(os.path.join(dst, f"mask_{i}.png"))
     print(f"cleaned {len(cleaned)} masks -> {dst}")

@@ -61,13 +61,16 @@ def run_inklayer_pipeline(input_path, out_base_dir, no_intermediate=False, inpai
     _draw_boxes(input_pil, boxes_int).save(os.path.join(out_dir, "bboxes.png"))
     input_pil.save(os.path.join(out_dir, "input.png"))
 
-    # Refinement (runner.py:69-73).  Mask cleanup + sketch NMS run on the GPU with the masks handed over IN MEMORY
-    # (the files masks_cleaned/ and bboxes_final.json are still written: they are part of the output tree); the
-    # depth map comes from the GPU Depth-Anything-V2 engine; the depth ordering / mask growth / box assignment are
-    # sequential algorithms and run on the host as in the reference (inklayer_amd/refine_host.py).
-    from InkLayer.refinement.mask_cleaner import run_clean_masks_on_sketch_dir, clean_masks_in_memory
+    # Refinement (runner.py:69-73).  Mask cleanup, sketch NMS, Depth-Anything-V2 and the refinement stage (depth order,
+    # disjoint parsing, growth, unlabeled mask) run on the GPU with the cleaned masks staying IN HBM from stage to stage
+    # (the files masks_cleaned/, bboxes_final.json, masks_disjoint/, masks_final/ are still written: they are part of the
+    # output tree); only the stroke thinning and the raster-order box assignment are host code (inklayer_amd/refine_stage.py).
+    from InkLayer.refinement.mask_cleaner import run_clean_masks_on_sketch_dir, clean_masks_on_device
     from InkLayer.refinement.bbox_filter import run_postprocess_boxes_on_sketch_dir
-    cleaned = clean_masks_in_memory(masks_np)
+    cleaned = clean_masks_on_device(masks_np)
+    if cleaned is None:
+        import numpy as _np
+        cleaned = _np.zeros((0,) + input_pil.size[::-1], _np.uint8)
     run_clean_masks_on_sketch_dir(out_dir, cleaned=cleaned)
     bbox_out_path = run_postprocess_boxes_on_sketch_dir(out_dir, sketch_iou_thresh=0.2, cleaned_masks=cleaned)
     from InkLayer.refinement.refiner import run_refinement_on_sketch_dir

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define INK_ABI_VERSION 3
+#define INK_ABI_VERSION 4
 int ink_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -339,6 +339,82 @@ int ink_mask_cleanup(const void* masks_u8, int32_t n, int32_t H, int32_t W, int3
  * sketch_rgb_u8: [H, W, 3] (the masks have the sketch's size on this path); bits_ws: uint64[n * ceil(H*W/64)]. */
 int ink_mask_sketch_iou_counts(const void* masks_u8, const void* sketch_rgb_u8, int32_t n, int32_t H, int32_t W,
                                void* bits_ws_u64, int32_t* counts, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Refinement stage on resident masks: depth ordering support, disjoint parsing, mask growth, box
+ * assignment support, the "unlabeled" extra mask.  Integer / bit work, bit-exact with the reference.
+ * Binary images are ROW-ALIGNED BIT PLANES: Wp = ceil(W / 64) uint64 words per row, bit b of word w of row y = pixel
+ * (y, 64 w + b), tail bits 0; n planes are [n, H, Wp].  Mask sets after the disjoint parsing are ONE uint8 label image
+ * [H, W] (label l = mask index l - 1, 0 = no mask; at most 254 masks).  H, W <= 16383.
+ *
+ * ink_refine_sketch_planes: sketch RGB u8 [H, W, 3] -> 4 planes
+ *   0: sketch_to_01binary of the cv2 BGR image (InkLayer/refinement/utils.py:3-9): blue <= max(all bytes) / 2
+ *   1: PIL luma <  250 (refiner.py:106-110)        2: PIL luma <= 250 (refiner.py:134, 246)
+ *   3: cv2 gray <  250 (refiner.py:302-303)        max_ws: int32[1] scratch. */
+int ink_refine_sketch_planes(const void* rgb_u8, int32_t H, int32_t W, void* planes4_u64, int32_t* max_ws, void* stream);
+
+/* uint8 images [n, H, W] -> planes (pixel > thresh). */
+int ink_bitplane_pack(const void* img_u8, int32_t n, int32_t H, int32_t W, int32_t thresh, void* planes_u64, void* stream);
+
+/* get_mask_depth_score's inputs (depth_sort.py:72-89): vals[p] = depth[pts[p]] and inside[m, p] = mask m covers sample p
+ * (uint8 [n, P]); pts_yx int32 [P, 2] (y, x).  The binned mode itself is a few hundred numbers: host. */
+int ink_refine_depth_samples(const void* mask_planes, int32_t n, const float* depth, const int32_t* pts_yx, int32_t P,
+                             int32_t H, int32_t W, float* vals, void* inside_u8, void* stream);
+
+/* All pair / per-mask counts the ordering and the disjoint parsing need, in one pass over the planes:
+ *   D_m = cv2.dilate(mask_m & plane 0, 3x3 ellipse) (depth_sort.py:193-197)
+ *   pair[i, j] = (|M_i & M_j| over the image (refiner.py:71-74), |D_i & D_j| inside rect[i, j] (depth_sort.py:222-231))
+ *   per_mask[m] = (|M_m| (refiner.py:41), |D_m| (depth_sort.py:200), |M_m & plane 1| (refiner.py:108-110))
+ *   sketch_area = |plane 1| (refiner.py:106)
+ * rect int32 [n, n, 4] = (y0, y1, x0, x1): the pair's box intersection as RESOLVED numpy slice bounds (half open,
+ * inside the image; the host applies numpy's rules for negative / oversized indices).  dil_ws: n planes of scratch.
+ * pair int32 [n, n, 2], per_mask int32 [n, 3]. */
+int ink_refine_pair_tables(const void* mask_planes, const void* sketch_planes4, int32_t n, int32_t H, int32_t W,
+                           const int32_t* rect, void* dil_ws_planes, int32_t* pair, int32_t* per_mask,
+                           int32_t* sketch_area, void* stream);
+
+/* composite_and_parse_masks' layering (refiner.py:44-47): label = 1 + the first rank r whose mask order[r] covers the
+ * pixel (order[r] < 0: rank emptied by the "covers the whole sketch" rule, refiner.py:104-112); hist256[l] = pixels. */
+int ink_refine_composite(const void* mask_planes, const int32_t* order, int32_t n_ranks, int32_t H, int32_t W,
+                         void* label_u8, int32_t* hist256, void* stream);
+
+/* out = clean_delicate_mask (refiner.py:21-33) of every mask of map256[label]: a pixel with at most one 8-neighbour of
+ * its own (mapped) label is cleared.  map256: uint8[256] on the device (0 drops a label). */
+int ink_refine_relabel_clean(const void* label_u8, const void* map256_u8, int32_t H, int32_t W, void* out_label_u8,
+                             void* stream);
+
+/* refine_masks_with_watershed (refiner.py:129-196) on the label image: unlabeled stroke pixels (plane 2, label 0),
+ * their closing by disk(3), its 4-connected components of more than 50 pixels ("large regions"), masks within disk(3)
+ * of one grow by disk(3) (flags256[l] = 1), the others by disk(2); where several masks reach a pixel the largest label
+ * wins; everything restricted to plane 2.  Also returns what refine_masks_with_boxes needs: bbox256x4[l] = (xmin, ymin,
+ * xmax, ymax) of grown mask l ((W, H, -1, -1) if empty) and the still unlabeled stroke pixels in raster order
+ * (unl_yx int32 [unl_cap, 2], *unl_count = their number, possibly > unl_cap).
+ * planes_ws / cc_ws sizes: ink_refine_grow_workspace. */
+int ink_refine_grow_workspace(int32_t H, int32_t W, int64_t* plane_words, int64_t* cc_ints);
+int ink_refine_grow(const void* label_u8, const void* sketch_planes4, int32_t H, int32_t W, void* planes_ws,
+                    int32_t* cc_ws, int32_t* flags256, void* out_label_u8, int32_t* bbox256x4, int32_t* unl_yx,
+                    int32_t unl_cap, int32_t* unl_count, void* stream);
+
+/* d2[q, l] = squared distance from pixel q_yx[q] to the nearest pixel of label l for the labels in cand (4 uint64 per
+ * query = a 256-bit set), 0x7fffffff where the label has no pixel (`np.min(distances)` of refiner.py:277-281). */
+int ink_refine_query_dists(const void* label_u8, const int32_t* q_yx, const void* cand256_bits, int32_t Q, int32_t H,
+                           int32_t W, int32_t* d2_Qx256, void* stream);
+
+/* Applies the assignments (y, x, label) of the raster-order loop to the label image (in place), then
+ * create_unlabeled_mask (refiner.py:301-337): plane 3 minus the labelled pixels, cv2 MORPH_OPEN 3x3, cv2.dilate 2x2
+ * -> extra_plane, *extra_count = its pixel count.  planes_ws3: 3 planes of scratch. */
+int ink_refine_finalize(void* label_u8, const int32_t* assign_yxl, int32_t A, const void* sketch_planes4, int32_t H,
+                        int32_t W, void* planes_ws3, void* extra_plane, int32_t* extra_count, void* stream);
+
+/* HOST functions (host pointers, no GPU work): the two sequential algorithms of the stage.
+ * ink_host_sparse_sample = sparse_sketch_sample (depth_sort.py:49-68) of the sketch (RGB u8 [H, W, 3]): greedy
+ * row-major thinning of the plane-0 pixels with radius 0.01 H; out_yx int32 [cap, 2], *count = samples found.
+ * ink_host_assign_unlabeled = the pixel loop of refine_masks_with_boxes (refiner.py:262-295): q_yx the unlabeled stroke
+ * pixels in raster order, boxes int32 [nb, 4] (inclusive), box2mask[nb] (-1: unmatched), d2 int32 [Q, 256] from
+ * ink_refine_query_dists, nonempty uint8 [n_masks]; out_label[q] = 1 + mask index, 0 = stays unlabeled. */
+int ink_host_sparse_sample(const uint8_t* rgb_u8, int32_t H, int32_t W, int32_t* out_yx, int32_t cap, int32_t* count);
+int ink_host_assign_unlabeled(const int32_t* q_yx, int32_t Q, const int32_t* boxes, int32_t nb, const int32_t* box2mask,
+                              const int32_t* d2, const uint8_t* nonempty, int32_t n_masks, int32_t* out_label);
 
 /* ------------------------------------------------------------------------
  * Depth-Anything-V2 ViT-B pixel-side ops (the dense layers reuse ink_gemm_f16 / ink_flash_attn /

@@ -83,6 +83,20 @@ SIGNATURES = {
     "ink_mask_cleanup": [c_void_p, c_int, c_int, c_int, c_int, c_int, C.c_double, c_void_p, c_void_p, c_void_p,
                          c_void_p, c_void_p],
     "ink_mask_sketch_iou_counts": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "ink_refine_sketch_planes": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "ink_bitplane_pack": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ink_refine_depth_samples": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "ink_refine_pair_tables": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p],
+    "ink_refine_composite": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "ink_refine_relabel_clean": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "ink_refine_grow_workspace": [c_int, c_int, C.POINTER(c_i64), C.POINTER(c_i64)],
+    "ink_refine_grow": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                        c_int, c_void_p, c_void_p],
+    "ink_refine_query_dists": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ink_refine_finalize": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ink_host_sparse_sample": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
+    "ink_host_assign_unlabeled": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "ink_depth_patchify": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                            c_int, c_void_p, c_void_p],
     "ink_resize_bilinear_ac_nhwc": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],

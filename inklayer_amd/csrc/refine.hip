@@ -4,7 +4,7 @@
 //   reference: InkLayer/refinement/mask_cleaner.py:11-36  (threshold -> MORPH_CLOSE with a k x k rect -> 8-connected
 //              components with stats -> keep area > 500 or aspect ratio > 1.1)
 //              InkLayer/refinement/nms_sketch.py:62-78,186-234 (masks AND stroke pixels, |A&B| / |A|B| per pair)
-#include "common.h"
+#include "bitplane.h"
 #include "../../include/inklayer_hip.h"
 
 namespace {
@@ -82,167 +82,6 @@ __global__ __launch_bounds__(256) void box_cols_kernel(const uint8_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// 8-connected components with stats + the area / aspect-ratio filter, RUN based, one workgroup per mask.
-// Workspace per mask (int32): nruns[H] | run[H*RM] (start | end << 16) | parent[H*RM] | area | xmin | xmax | ymin | ymax
-// (each [H*RM]); run id = y * RM + index in row.  After a k x k closing every background gap in a row is at least
-// (k+1)/2 pixels long, so RM = W / ((k+1)/2 + 1) + 2 bounds the runs of a row (ink_mask_cleanup sizes it so).
-__device__ __forceinline__ int cc_find(volatile int* parent, int x) {
-  int p = parent[x];
-  while (p != x) {
-    x = p;
-    p = parent[x];
-  }
-  return x;
-}
-__device__ __forceinline__ void cc_union(int* parent, int a, int b) {
-  while (true) {
-    a = cc_find(parent, a);
-    b = cc_find(parent, b);
-    if (a == b) return;
-    if (a < b) { const int t = a; a = b; b = t; }           // hook the larger root under the smaller one
-    const int old = atomicMin(&parent[a], b);
-    if (old == a) return;
-    a = old;
-  }
-}
-
-__global__ __launch_bounds__(1024) void components_filter_kernel(const uint8_t* __restrict__ closed,
-                                                                 uint8_t* __restrict__ out, int H, int W, int RM,
-                                                                 int area_thr, double aspect_thr,
-                                                                 int* __restrict__ ws_all, int64_t ws_stride,
-                                                                 int* __restrict__ overflow) {
-  const int64_t m = blockIdx.x;
-  const uint8_t* img = closed + m * H * W;
-  uint8_t* dst = out + m * H * W;
-  int* ws = ws_all + m * ws_stride;
-  int* nruns = ws;
-  int* run = nruns + H;
-  const int64_t NR = (int64_t)H * RM;
-  int* parent = run + NR;
-  int* area = parent + NR;
-  int* xmin = area + NR;
-  int* xmax = xmin + NR;
-  int* ymin = xmax + NR;
-  int* ymax = ymin + NR;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
-
-  // A. runs of every row: one wave per row, 64 pixels per step, transitions from the ballot of the foreground bits
-  for (int y = wave; y < H; y += nwave) {
-    const uint8_t* rp = img + (int64_t)y * W;
-    int n = 0, open_start = -1;
-    for (int x0 = 0; x0 < W; x0 += 64) {
-      const int x = x0 + lane;
-      const bool fg = x < W && rp[x] != 0;
-      unsigned long long bits = __ballot(fg);
-      // every lane walks the same transitions (uniform control flow, no divergence)
-      int pos = 0;
-      while (pos < 64) {
-        if (open_start < 0) {
-          const unsigned long long rest = pos < 64 ? (bits >> pos) : 0ull;
-          if (rest == 0ull) break;
-          pos += __builtin_ctzll(rest);
-          open_start = x0 + pos;
-        } else {
-          const unsigned long long rest = ~bits >> pos;        // first background bit at or after pos
-          const int z = pos < 64 && rest != 0ull ? __builtin_ctzll(rest) : 64;
-          if (pos + z >= 64) { pos = 64; break; }              // run continues into the next 64-pixel group
-          pos += z;
-          if (n < RM) {
-            if (lane == 0) run[(int64_t)y * RM + n] = open_start | ((x0 + pos - 1) << 16);
-          } else if (lane == 0) {
-            atomicOr(overflow, 1);
-          }
-          n = n < RM ? n + 1 : n;
-          open_start = -1;
-        }
-      }
-    }
-    if (open_start >= 0) {                                     // run touching the right border
-      if (n < RM) {
-        if (lane == 0) run[(int64_t)y * RM + n] = open_start | ((W - 1) << 16);
-        ++n;
-      } else if (lane == 0) {
-        atomicOr(overflow, 1);
-      }
-    }
-    if (lane == 0) nruns[y] = n;
-    for (int i = lane; i < n; i += 64) {
-      const int64_t id = (int64_t)y * RM + i;
-      parent[id] = (int)id;
-      area[id] = 0;
-      xmin[id] = W;
-      xmax[id] = -1;
-      ymin[id] = H;
-      ymax[id] = -1;
-    }
-  }
-  __syncthreads();
-  // B. union of 8-connected runs of adjacent rows: [s, e] touches [s', e'] of the row above iff s' <= e + 1 and
-  //    e' >= s - 1.  One thread per row, two-pointer walk over the two sorted run lists.
-  for (int y = 1 + tid; y < H; y += blockDim.x) {
-    const int na = nruns[y], nb = nruns[y - 1];
-    int j = 0;
-    for (int i = 0; i < na; ++i) {
-      const int ra = run[(int64_t)y * RM + i];
-      const int s = ra & 0xffff, e = ra >> 16;
-      while (j < nb && (run[(int64_t)(y - 1) * RM + j] >> 16) < s - 1) ++j;
-      int jj = j;
-      while (jj < nb) {
-        const int rb = run[(int64_t)(y - 1) * RM + jj];
-        if ((rb & 0xffff) > e + 1) break;
-        cc_union(parent, y * RM + i, (y - 1) * RM + jj);
-        ++jj;
-      }
-    }
-  }
-  __syncthreads();
-  // C + D. flatten, accumulate area and bounding box per root
-  for (int y = wave; y < H; y += nwave) {
-    const int n = nruns[y];
-    for (int i = lane; i < n; i += 64) {
-      const int id = y * RM + i;
-      const int root = cc_find(parent, id);
-      parent[id] = root;
-      const int ra = run[id];
-      const int s = ra & 0xffff, e = ra >> 16;
-      atomicAdd(&area[root], e - s + 1);
-      atomicMin(&xmin[root], s);
-      atomicMax(&xmax[root], e);
-      atomicMin(&ymin[root], y);
-      atomicMax(&ymax[root], y);
-    }
-  }
-  __syncthreads();
-  // E. decision per root (in place: area[root] becomes 1 = keep / 0 = drop)
-  for (int y = wave; y < H; y += nwave) {
-    const int n = nruns[y];
-    for (int i = lane; i < n; i += 64) {
-      const int id = y * RM + i;
-      if (parent[id] == id) {
-        const int w = xmax[id] - xmin[id] + 1, h = ymax[id] - ymin[id] + 1;
-        const double ar = (double)(w > h ? w : h) / ((double)(w < h ? w : h) + 1e-5);
-        xmin[id] = (area[id] > area_thr || ar > aspect_thr) ? 1 : 0;     // xmin doubles as the keep flag from here on
-      }
-    }
-  }
-  __syncthreads();
-  // F. output: one wave per row, coalesced; zero the row, then paint the kept runs with 255
-  for (int y = wave; y < H; y += nwave) {
-    uint8_t* op = dst + (int64_t)y * W;
-    for (int x = lane; x < W; x += 64) op[x] = 0;
-    const int n = nruns[y];
-    for (int i = 0; i < n; ++i) {
-      const int id = y * RM + i;
-      if (xmin[parent[id]] != 0) {
-        const int ra = run[id];
-        const int s = ra & 0xffff, e = ra >> 16;
-        for (int x = s + lane; x <= e; x += 64) op[x] = 255;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // Sketch NMS table.  refined_m = (mask_m > 0) AND (luma(sketch) < 250)  (refine_mask_to_sketch_regions), bit-packed
 // 64 pixels per word by wave ballot; then counts[i, j] = (popcount(r_i & r_j), popcount(r_i | r_j)).
 __global__ __launch_bounds__(256) void pack_refined_kernel(const uint8_t* __restrict__ masks,
@@ -294,11 +133,13 @@ __global__ __launch_bounds__(256) void pair_counts_kernel(const unsigned long lo
 
 }  // namespace
 
+// After a k x k closing every background gap of a row is at least (k+1)/2 pixels long, so a row has at most
+// RM = W / ((k+1)/2 + 1) + 2 runs: that sizes the components workspace (an overflow flag guards it all the same).
+static inline int cleanup_rm(int W, int k) { return W / ((k + 1) / 2 + 1) + 2; }
+
 extern "C" int ink_mask_cleanup_workspace_ints(int32_t n, int32_t H, int32_t W, int32_t k, int64_t* out_ints) {
   INK_CHECK_ARG(out_ints && n > 0 && H > 0 && W > 0 && k >= 1 && k % 2 == 1);
-  const int gap = (k + 1) / 2;                       // shortest background gap of a row after a k x k closing
-  const int64_t RM = W / (gap + 1) + 2;
-  *out_ints = 1 + (int64_t)n * ((int64_t)H + 7 * (int64_t)H * RM);    // [0] = overflow flag, then n per-mask blocks
+  *out_ints = 1 + (int64_t)n * cc_ws_ints_per_plane(H, cleanup_rm(W, k));   // [0] = overflow flag, then n per-mask blocks
   return INK_OK;
 }
 
@@ -320,14 +161,18 @@ extern "C" int ink_mask_cleanup(const void* masks_u8, int32_t n, int32_t H, int3
   hipLaunchKernelGGL(box_cols_kernel, cgrid, dim3(256), 0, s, a, b, H, W, r, 0, seg);
   hipLaunchKernelGGL(box_rows_kernel, dim3(n * H), dim3(256), lds, s, b, a, W, r, 1, 0);
   hipLaunchKernelGGL(box_cols_kernel, cgrid, dim3(256), 0, s, a, b, H, W, r, 1, seg);
-  const int gap = (k + 1) / 2;
-  const int RM = W / (gap + 1) + 2;
-  const int64_t stride = (int64_t)H + 7 * (int64_t)H * RM;
-  // workspace[0] = overflow flag (stays 0 by construction; checked by the host wrapper in debug runs)
+  // 8-connected components of the closed masks with area / aspect filter: the closed 0/1 bytes are packed into bit
+  // planes (they live in the first scratch image, which is free again: 8 ceil(W/64) <= W bytes per row from W = 8 on)
+  // and labelled by the multi-workgroup run-based passes of bitplane.h; the kept runs are painted straight into
+  // out_u8 as 0 / 255.
+  const int Wp = (W + 63) / 64;
+  INK_CHECK_ARG((int64_t)Wp * 8 <= (int64_t)W);
+  u64* planes = (u64*)a;
+  INK_CHECK_ARG(((uintptr_t)planes & 7) == 0);
+  hipLaunchKernelGGL(bp_pack_kernel, dim3((H * Wp + 3) / 4, n), dim3(256), 0, s, (const uint8_t*)b, H, W, Wp, 0, planes);
   if (hipMemsetAsync(workspace, 0, sizeof(int32_t), s) != hipSuccess) return INK_ERR_LAUNCH;
-  hipLaunchKernelGGL(components_filter_kernel, dim3(n), dim3(1024), 0, s, b, (uint8_t*)out_u8, H, W, RM,
-                     area_threshold, aspect_threshold, workspace + 1, stride, workspace);
-  return ink_launch_status();
+  return cc_run(planes, (int64_t)H * Wp, n, H, W, Wp, cleanup_rm(W, k), 1, area_threshold, aspect_threshold,
+                workspace + 1, workspace, (uint8_t*)out_u8, nullptr, 0, s);
 }
 
 extern "C" int ink_mask_sketch_iou_counts(const void* masks_u8, const void* sketch_rgb_u8, int32_t n, int32_t H,

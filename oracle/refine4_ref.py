@@ -1,20 +1,16 @@
-"""Host side of InkLayer's refinement stage: depth ordering of the masks, disjoint parsing, growth of
-the masks over unlabeled stroke pixels, per-pixel box assignment, the "unlabeled" extra mask.
+"""oracle/refine4_ref.py - TEST INFRASTRUCTURE ONLY (the checker of SURVEY §8(f)-4; the product is
+inklayer_amd/refine_stage.py + csrc/refine_stage.hip and never imports this file).
+
+A numpy / scipy restatement, function by function, of InkLayer's refinement stage: depth ordering of the masks, disjoint
+parsing, growth of the masks over unlabeled stroke pixels, per-pixel box assignment, the "unlabeled" extra mask.
 
 Reference: InkLayer/refinement/depth_sort.py:49-270 (sparse_sketch_sample, get_mask_depth_score,
 build_containment_graph_fast, compute_major_overlap_matrix, sort_sketch_masks) and InkLayer/refinement/refiner.py:21-337
 (clean_delicate_mask, composite_and_parse_masks, parse_masks_to_disjoint_masks, refine_masks_with_watershed,
-match_masks_to_boxes, refine_masks_with_boxes, create_unlabeled_mask), refinement/utils.py.
-
-This stage stays on the HOST, as in the reference, and that is a property of the algorithms, not a shortcut:
-  * `refine_masks_with_boxes` assigns the unlabeled stroke pixels in raster order and every assignment changes the
-    "nearest filled pixel" distances of the pixels after it;
-  * `sparse_sketch_sample` is a greedy sequential thinning (take a point, drop its neighbours, repeat);
-  * the greedy reorder loop of `sort_sketch_masks` and the merge rule of `composite_and_parse_masks` are sequential
-    over a few dozen masks.
-None has a parallel form with bit-identical results; the per-mask image operations they are made of are a few ms of
-numpy / scipy.ndimage on 750^2..1024^2 bool arrays.  (The depth MAP they consume is computed on the GPU:
-inklayer_amd/depth.py.)
+match_masks_to_boxes, refine_masks_with_boxes, create_unlabeled_mask), refinement/utils.py.  It follows the reference's
+structure closely on purpose: one function per reference function, the same loops over masks, so that a disagreement with
+the HIP stage can be localised.  (Rounds 1-2 shipped this file as the product's host stage; it was retired to a checker
+when the stage moved to the GPU.)
 
 cv2 / skimage are not importable here; their functions are restated from their published algorithms:
   * skimage.morphology.disk / binary_dilation / binary_closing -> scipy.ndimage with skimage's border rule (dilation
@@ -25,8 +21,8 @@ cv2 / skimage are not importable here; their functions are restated from their p
     gradient images the reference computes for it (refiner.py:171-189) do not influence the result and are not computed;
   * cv2.morphologyEx(MORPH_OPEN, ones(3,3)), cv2.dilate(ones(2,2)) (anchor (1,1): the window reaches up / left),
     cv2.getStructuringElement(MORPH_ELLIPSE, (3,3)) = the 3x3 cross, cv2.imread(GRAYSCALE) = libpng's rgb_to_gray.
-Pinned by the reference's own committed outputs (masks_disjoint/ -> masks_final/ of its 7 output sets), see
-tests/test_refiner_cpu.py.
+PINNED by the reference's own committed outputs (masks_cleaned/ -> masks_disjoint/ -> masks_final/ of its 7 output
+sets, tests/golden/refine_*.npz): tests/test_oracle_refine4.py.
 """
 from __future__ import annotations
 

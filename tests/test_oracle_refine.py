@@ -60,7 +60,7 @@ def test_luma_formulas_match_pillow():
     host stage's and (through tests/test_refine_gpu.py) the GPU kernel's fixed-point formula must reproduce Pillow."""
     from PIL import Image
     from oracle import refine_ref
-    from inklayer_amd import refine_host
+    from oracle import refine4_ref as refine_host
     rs = np.random.RandomState(1)
     rgb = rs.randint(0, 256, size=(257, 301, 3)).astype(np.uint8)
     rgb[:8, :8] = [[250, 250, 250]]; rgb[8:16, :8] = [[249, 250, 251]]       # values around the 250 threshold

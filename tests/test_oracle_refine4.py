@@ -1,5 +1,6 @@
-"""Row (f)-4: inklayer_amd/refine_host.py (depth-order based disjoint parsing, mask growth, per-pixel box assignment,
-the unlabeled extra mask) against the reference's OWN committed outputs (tests/golden/refine_*.npz:
+"""Row (f)-4, the CHECKER: oracle/refine4_ref.py (the numpy / scipy restatement of the depth-order based disjoint parsing,
+mask growth, per-pixel box assignment and the unlabeled extra mask that tests/test_refine_stage_gpu.py compares the HIP
+stage with) against the reference's OWN committed outputs (tests/golden/refine_*.npz:
 masks_cleaned/ + bboxes_final.json -> masks_disjoint/ -> masks_final/ of its 7 output sets), bit for bit.
 
 Stage B (masks_disjoint -> masks_final: refiner.py:129-372) needs nothing but the fixtures.  Stage A (masks_cleaned ->
@@ -27,7 +28,7 @@ def _load(path):
 
 @pytest.mark.parametrize("path", GOLD, ids=lambda p: Path(p).stem)
 def test_stage_b_reproduces_reference_masks_final(path):
-    from inklayer_amd import refine_host as R
+    from oracle import refine4_ref as R
     g, h, w, unpack = _load(path)
     dis = unpack(g["masks_disjoint"])[g["masks_disjoint_present"]]
     fin = unpack(g["masks_final"])[g["masks_final_present"]]
@@ -49,7 +50,7 @@ def test_stage_b_reproduces_reference_masks_final(path):
 
 @pytest.mark.parametrize("path", GOLD, ids=lambda p: Path(p).stem)
 def test_stage_a_reproduces_reference_masks_disjoint_under_the_recovered_depth_order(path):
-    from inklayer_amd import refine_host as R
+    from oracle import refine4_ref as R
     g, h, w, unpack = _load(path)
     cleaned = unpack(g["masks_cleaned"])
     dis = unpack(g["masks_disjoint"])[g["masks_disjoint_present"]]
@@ -80,7 +81,7 @@ def test_stage_a_reproduces_reference_masks_disjoint_under_the_recovered_depth_o
 def test_depth_ordering_on_synthetic_depth():
     """sort_sketch_masks: deepest (largest binned depth mode over the sparse stroke samples) first; a containing box is
     moved in front of a box it contains when their stroke masks overlap."""
-    from inklayer_amd import refine_host as R
+    from oracle import refine4_ref as R
     H = W = 200
     rgb = np.full((H, W, 3), 255, np.uint8)
     rgb[20:180, 20:24] = 0; rgb[20:180, 176:180] = 0; rgb[20:24, 20:180] = 0; rgb[176:180, 20:180] = 0    # big frame
@@ -128,10 +129,10 @@ def _sparse_sketch_sample_literal(binary_edge_map):
 @pytest.mark.parametrize("name", ["bunny_cook_sketch", "animal_hike_sketch", "office_sketch", "clock_lamp_plant",
                                   "fscoco_animals", "mario_bunny", "Clipasso_brushpen_0249"])
 def test_fast_host_forms_equal_the_literal_ones(name):
-    """refine_host's index-image thinning and shifted-sum neighbour count against the reference's literal forms (set +
+    """the oracle's index-image thinning and shifted-sum neighbour count against the reference's literal forms (set +
     KD-tree; scipy convolve with the 3x3 ring) on the reference's own sketches and cleaned masks: identical output."""
     from scipy import ndimage
-    from inklayer_amd import refine_host as R
+    from oracle import refine4_ref as R
     z = np.load(str(Path(__file__).resolve().parent / "golden" / f"refine_{name}.npz"))
     rgb = z["input"]
     binary = R.sketch_to_01binary(rgb[..., ::-1])
@@ -150,7 +151,7 @@ def test_window_morphology_equals_scipy():
     """sk_dilate / sk_erode (shifts of the mask's window) against scipy's generic routines with skimage's border
     conventions, on random masks that touch the image border and on every structuring element the stage uses."""
     from scipy import ndimage
-    from inklayer_amd import refine_host as R
+    from oracle import refine4_ref as R
     rs = np.random.RandomState(1)
     sts = (R.disk(1), R.disk(2), R.disk(3), ndimage.generate_binary_structure(2, 1), np.ones((3, 3), bool))
     for t in range(150):

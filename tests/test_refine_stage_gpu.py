@@ -1,0 +1,214 @@
+"""Row (f)-4 on the HIP path: inklayer_amd/refine_stage.py + csrc/refine_stage.hip (bit planes, label image, multi-workgroup
+connected components) bit for bit against
+
+  * the reference's OWN committed outputs (tests/golden/refine_*.npz: masks_cleaned/ + bboxes_final.json ->
+    masks_disjoint/ -> masks_final/ of its 7 output sets): stage B directly, stage A under the depth order recovered
+    from the fixtures (the reference's depth scores need the real Depth-Anything checkpoint);
+  * the checker oracle/refine4_ref.py (itself pinned by those fixtures, tests/test_oracle_refine4.py) on the whole stage
+    incl. the depth ordering, with synthetic depth maps, random masks of odd sizes, empty / degenerate inputs.
+GPU box only."""
+import glob
+import itertools
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = sorted(glob.glob(str(Path(__file__).resolve().parent / "golden" / "refine_*.npz")))
+
+
+def _load(path):
+    g = np.load(path)
+    h, w = (int(v) for v in g["hw"])
+    unpack = lambda a: np.unpackbits(a, axis=-1)[..., :w].astype(bool)
+    return g, h, w, unpack
+
+
+def _dev_masks(masks, dev):
+    return torch.from_numpy(np.ascontiguousarray(np.stack(masks).astype(np.uint8))).to(dev)
+
+
+def _sketch_planes(rgb, dev):
+    from inklayer_amd import _lib, ops
+    H, W = rgb.shape[:2]
+    sk = torch.empty((4, H, (W + 63) // 64), device=dev, dtype=torch.int64)
+    ws = torch.zeros(1, device=dev, dtype=torch.int32)
+    _lib.check(_lib.lib().ink_refine_sketch_planes(torch.from_numpy(np.ascontiguousarray(rgb)).to(dev).data_ptr(), H, W,
+                                                   sk.data_ptr(), ws.data_ptr(), ops._stream()), "planes")
+    return sk
+
+
+def _unpack_planes(sk, W):
+    a = sk.cpu().numpy().view(np.uint64)
+    return np.unpackbits(a.view(np.uint8).reshape(a.shape[0], a.shape[1], -1), axis=2, bitorder="little")[:, :, :W].astype(bool)
+
+
+@pytest.mark.parametrize("path", GOLD, ids=lambda p: Path(p).stem)
+def test_sketch_planes_and_stage_b_reproduce_reference_masks_final(dev, path):
+    from inklayer_amd import refine_stage as S
+    from oracle import refine4_ref as R
+    g, h, w, unpack = _load(path)
+    rgb = g["input"]
+    sk = _sketch_planes(rgb, dev)
+    pl = _unpack_planes(sk, w)
+    luma = R.pil_luma(rgb)
+    assert np.array_equal(pl[0], R.sketch_to_01binary(rgb[..., ::-1]) > 0)
+    assert np.array_equal(pl[1], luma < 250) and np.array_equal(pl[2], ~(luma > 250)) and np.array_equal(pl[3], R.png_gray(rgb) < 250)
+    dis = unpack(g["masks_disjoint"])[g["masks_disjoint_present"]]
+    fin = unpack(g["masks_final"])[g["masks_final_present"]]
+    boxes = R.unnormalize_bboxes(g["final_bboxes"].tolist(), h, w)
+    used, order = set(), []
+    for bb in (R.compute_mask_bbox(m) for m in dis):          # boxes in depth order = the order of the disjoint files
+        j = int(np.argmax([(R.compute_bbox_iou(boxes[j], bb) if j not in used else -1) for j in range(len(boxes))]))
+        used.add(j)
+        order.append(j)
+    order += [j for j in range(len(boxes)) if j not in used]
+    label = np.zeros((h, w), np.uint8)
+    for i, m in enumerate(dis):
+        label[m] = i + 1
+    final, extra = S.grow_and_assign(torch.from_numpy(label).to(dev), len(dis), [boxes[j] for j in order], sk)
+    out = [final == l for l in range(1, len(dis) + 1)] + ([extra] if extra is not None else [])
+    assert len(out) == len(fin)
+    for i, (o, f) in enumerate(zip(out, fin)):
+        assert np.array_equal(o, f), f"masks_final/mask_{i}.png differs in {int((o != f).sum())} pixels"
+
+
+@pytest.mark.parametrize("path", GOLD, ids=lambda p: Path(p).stem)
+def test_stage_a_reproduces_reference_masks_disjoint_under_the_recovered_depth_order(dev, path):
+    from inklayer_amd import refine_stage as S
+    from oracle import refine4_ref as R
+    g, h, w, unpack = _load(path)
+    cleaned = unpack(g["masks_cleaned"])
+    dis = unpack(g["masks_disjoint"])[g["masks_disjoint_present"]]
+    kept = g["final_kept"].tolist()
+    boxes = R.unnormalize_bboxes(g["final_bboxes"].tolist(), h, w)
+    masks = [cleaned[k].astype(np.uint8) * 255 for k in kept]
+    used, order = set(), []
+    for d in dis:                                    # the tightest unused cleaned mask that contains the disjoint mask
+        cand = [j for j in range(len(masks)) if j not in used and np.logical_and(d, masks[j] > 0).sum() == d.sum()]
+        j = min(cand, key=lambda j: int((masks[j] > 0).sum()))
+        used.add(j)
+        order.append(j)
+    rest = [j for j in range(len(masks)) if j not in used]      # masks that vanished / were merged: position unknown
+    dm = _dev_masks(masks, dev)
+    ok = False
+    for pos in itertools.product(range(len(order) + 1), repeat=len(rest)):
+        o = list(order)
+        for r, p in sorted(zip(rest, pos), key=lambda t: -t[1]):
+            o.insert(p, r)
+        res = S.refine_masks(dm, boxes, g["input"], None, order=o, stop_after_disjoint=True)
+        out = res.disjoint_masks()
+        if len(out) == len(dis) and all(np.array_equal(a, b) for a, b in zip(out, dis)):
+            ok = True
+            assert res.sorted_boxes == [boxes[j] for j in o]
+            want, wboxes, winfo = R.parse_masks_to_disjoint_masks(masks, boxes, g["input"], None, order=o)
+            assert [i["original_indices"] for i in res.info] == [i["original_indices"] for i in winfo]
+            break
+    assert ok
+
+
+def _synthetic_depth(h, w, seed):
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    d = 4.0 + 3.0 * np.sin(xx / (40.0 + 30 * rs.rand())) * np.cos(yy / (35.0 + 30 * rs.rand())) + 2.0 * (yy / h)
+    return (d + 0.02 * rs.standard_normal((h, w))).astype(np.float32)
+
+
+def _assert_stage_equals_oracle(dev, masks255, boxes, rgb, depth, tag=""):
+    from inklayer_amd import refine_stage as S
+    from oracle import refine4_ref as R
+    h, w = rgb.shape[:2]
+    worder, wscores, wcont = R.sort_sketch_masks([m > 0 for m in masks255], boxes, rgb, depth) if len(masks255) else ([], [], None)
+    wdis, wboxes, winfo = R.parse_masks_to_disjoint_masks(list(masks255), boxes, rgb, depth)
+    wfin = R.improve_sam_masks(rgb, wdis, wboxes)
+    dm = _dev_masks(masks255, dev) if len(masks255) else torch.zeros((0, h, w), dtype=torch.uint8, device=dev)
+    res = S.refine_masks(dm, boxes, rgb, torch.from_numpy(depth).to(dev))
+    assert res.order == [int(i) for i in worder], (tag, res.order, worder)
+    assert np.array_equal(np.asarray(res.scores, np.float64), np.asarray(wscores, np.float64))
+    assert res.sorted_boxes == [list(b) for b in wboxes]
+    got = res.disjoint_masks()
+    assert len(got) == len(wdis) and all(np.array_equal(a, b) for a, b in zip(got, wdis)), tag
+    assert [i["original_indices"] for i in res.info] == [i["original_indices"] for i in winfo]
+    fin = res.final_masks()
+    assert len(fin) == len(wfin), (tag, len(fin), len(wfin))
+    for i, (a, b) in enumerate(zip(fin, wfin)):
+        assert np.array_equal(a, np.asarray(b) > 0), f"{tag}: final mask {i} differs in {int((a != (np.asarray(b) > 0)).sum())} px"
+    return res
+
+
+@pytest.mark.parametrize("path", GOLD, ids=lambda p: Path(p).stem)
+def test_whole_stage_equals_the_checker_on_reference_masks_with_synthetic_depth(dev, path):
+    """Depth ordering included: the reference's cleaned masks and boxes, two synthetic depth maps each."""
+    from oracle import refine4_ref as R
+    g, h, w, unpack = _load(path)
+    cleaned = unpack(g["masks_cleaned"])
+    kept = g["final_kept"].tolist()
+    boxes = R.unnormalize_bboxes(g["final_bboxes"].tolist(), h, w)
+    masks = [cleaned[k].astype(np.uint8) * 255 for k in kept]
+    for seed in (0, 1):
+        res = _assert_stage_equals_oracle(dev, masks, boxes, g["input"], _synthetic_depth(h, w, seed), f"{Path(path).stem}/{seed}")
+    print(Path(path).stem, "order", res.order, "disjoint", res.n_disjoint, "extra", res.extra is not None)
+
+
+def test_whole_stage_on_random_masks_odd_sizes_and_edge_cases(dev):
+    """Salt-and-pepper / blob masks, widths that are not multiples of 64, boxes that stick out of the image, a mask
+    covering the whole sketch (the 90 % rule), nested boxes (containment reorder), no masks at all."""
+    from inklayer_amd import synthetic
+    rs = np.random.RandomState(7)
+    for t, (h, w) in enumerate(((97, 130), (200, 64), (333, 257), (150, 449), (64, 65))):
+        rgb = synthetic.synthetic_sketch(20 + t, h, w)
+        n = int(rs.randint(2, 9))
+        masks, boxes = [], []
+        for i in range(n):
+            x1, y1 = int(rs.randint(-3, w - 20)), int(rs.randint(-3, h - 20))
+            x2, y2 = int(min(w + 2, x1 + rs.randint(15, w))), int(min(h + 2, y1 + rs.randint(15, h)))
+            m = np.zeros((h, w), bool)
+            sub = m[max(y1, 0):max(y2, 0), max(x1, 0):max(x2, 0)]
+            sub[...] = rs.rand(*sub.shape) < (0.55 if i % 2 else 0.97)
+            masks.append(m.astype(np.uint8) * 255)
+            boxes.append([x1, y1, x2, y2])
+        if t == 1:                                   # a mask covering every stroke, and a box nested in the first one
+            masks[0][...] = 255
+            boxes[0] = [0, 0, w - 1, h - 1]
+            boxes[-1] = [10, 10, 30, 30]
+            masks[-1][...] = 0
+            masks[-1][10:30, 10:30] = 255
+        if t == 3:
+            masks[2][...] = 0                        # an empty mask
+        _assert_stage_equals_oracle(dev, masks, boxes, rgb, _synthetic_depth(h, w, 5 + t), f"random {h}x{w}")
+    rgb = synthetic.synthetic_sketch(3, 120, 200)
+    res = _assert_stage_equals_oracle(dev, [], [], rgb, _synthetic_depth(120, 200, 1), "no masks")
+    assert res.n_disjoint == 0 and res.extra is not None and len(res.final_masks()) == 1
+    one = np.zeros((120, 200), np.uint8)
+    one[30:90, 40:160] = 255
+    _assert_stage_equals_oracle(dev, [one], [[40, 30, 160, 90]], rgb, _synthetic_depth(120, 200, 2), "one mask")
+
+
+def test_plugin_surfaces_of_the_stage(dev, tmp_path):
+    """InkLayer.refinement.{depth_sort.sort_sketch_masks, refiner.parse_masks_to_disjoint_masks, improve_sam_masks}
+    with the reference's argument lists, on a PNG on disk."""
+    from PIL import Image
+    import InkLayer.refinement.depth_sort as DS
+    import InkLayer.refinement.refiner as RF
+    from oracle import refine4_ref as R
+    g, h, w, unpack = _load(GOLD[2])
+    png = tmp_path / "input.png"
+    Image.fromarray(g["input"]).save(png)
+    cleaned = unpack(g["masks_cleaned"])
+    kept = g["final_kept"].tolist()
+    boxes = R.unnormalize_bboxes(g["final_bboxes"].tolist(), h, w)
+    masks = [cleaned[k].astype(np.uint8) * 255 for k in kept]
+    depth = _synthetic_depth(h, w, 3)
+    order, scores, cont = DS.sort_sketch_masks(masks, boxes, str(png), depth_sketch=depth)
+    worder, wscores, wcont = R.sort_sketch_masks([m > 0 for m in masks], boxes, g["input"], depth)
+    assert order == [int(i) for i in worder] and np.array_equal(cont, wcont)
+    dis, sboxes, info = RF.parse_masks_to_disjoint_masks(masks, boxes, str(png), depth_map=depth)
+    wdis, wboxes, _ = R.parse_masks_to_disjoint_masks(masks, boxes, g["input"], depth)
+    assert len(dis) == len(wdis) and all(np.array_equal(a, b) for a, b in zip(dis, wdis)) and sboxes == wboxes
+    out = RF.improve_sam_masks(str(png), dis, sboxes)
+    wfin = R.improve_sam_masks(g["input"], wdis, wboxes)
+    assert len(out["final_masks"]) == len(wfin)
+    assert all(np.array_equal(np.asarray(a) > 0, np.asarray(b) > 0) for a, b in zip(out["final_masks"], wfin))

@@ -136,7 +136,8 @@ def test_runner_plugins_full_depth_against_oracle(dev, tmp_path, monkeypatch):
     # §8(f)-2 / -4 through the runner (config 5's stages): the depth map of the GPU engine against the depth oracle
     # on the same random weights, then masks_disjoint / masks_final against the host stage re-run on the ORACLE's depth
     from oracle import depth_ref
-    from inklayer_amd import depth as hip_depth, refine_host
+    from inklayer_amd import depth as hip_depth
+    from oracle import refine4_ref as refine_host
     import InkLayer.refinement.depth_sort as DS
     dcfg = depth_ref.DepthConfig()
     dsd = {k_: v.cpu() for k_, v in weights_init.random_depth_state_dict(hip_depth.DepthConfig(), "cuda").items()}

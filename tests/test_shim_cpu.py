@@ -76,7 +76,7 @@ def _fake_plugins(monkeypatch):
     # the refinement plugins run on the GPU too: on CPU the plumbing around them is what is tested
     import InkLayer.refinement.mask_cleaner as MC
     import InkLayer.refinement.bbox_filter as BF
-    monkeypatch.setattr(MC, "clean_masks_in_memory", lambda masks: np.stack([np.asarray(m, dtype=np.uint8) * 255 for m in masks]))
+    monkeypatch.setattr(MC, "clean_masks_on_device", lambda masks: np.stack([np.asarray(m, dtype=np.uint8) * 255 for m in masks]))
 
     def fake_nms(sketch_path, masks_dir, input_data, iou_threshold=0.2, cleaned_masks=None):
         assert cleaned_masks is not None and cleaned_masks.dtype == np.uint8      # handed over in memory
@@ -84,9 +84,26 @@ def _fake_plugins(monkeypatch):
                 "threshold": iou_threshold}
 
     monkeypatch.setattr(BF, "process_json_with_sketch_NMS", fake_nms)
-    import InkLayer.refinement.refiner as RF           # the depth model runs on the GPU: a synthetic depth map here
-    monkeypatch.setattr(RF, "get_depth_map", lambda path: np.tile(np.linspace(0, 3, Image.open(path).size[0], dtype=np.float32),
-                                                                  (Image.open(path).size[1], 1)))
+    # the depth model and the refinement stage run on the GPU: here a synthetic depth map and the CPU checker
+    # (oracle/refine4_ref.py) behind the stage's interface, so that the shim's hand-overs and file writing are exercised
+    import InkLayer.refinement.refiner as RF
+    from inklayer_amd import refine_stage
+    from oracle import refine4_ref
+    monkeypatch.setattr(RF, "get_depth_map_device", lambda path: torch.from_numpy(
+        np.tile(np.linspace(0, 3, Image.open(path).size[0], dtype=np.float32), (Image.open(path).size[1], 1))))
+    monkeypatch.setattr(RF, "_stack_on_gpu", lambda masks, shape: torch.from_numpy(
+        np.stack([(np.asarray(m) > 0) for m in masks]).astype(np.uint8)) if len(masks) else torch.zeros((0,) + tuple(shape), dtype=torch.uint8))
+
+    def fake_stage(masks, boxes, rgb, depth, **kw):
+        ms = [m.numpy() * 255 for m in masks]
+        dis, sboxes, info = refine4_ref.parse_masks_to_disjoint_masks(ms, boxes, rgb, depth.numpy())
+        fin = refine4_ref.improve_sam_masks(rgb, dis, sboxes)
+        lab = lambda lst: sum(((np.asarray(m) > 0).astype(np.uint8) * (i + 1) for i, m in enumerate(lst)),
+                              np.zeros(rgb.shape[:2], np.uint8))
+        extra = np.asarray(fin[-1]) > 0 if len(fin) > len(dis) else None
+        return refine_stage.RefineResult([], [], sboxes, lab(dis), len(dis), info, lab(fin[:len(dis)]), extra)
+
+    monkeypatch.setattr(refine_stage, "refine_masks", fake_stage)
 
 
 def _check_tree(out_dir, W, H):

@@ -39,7 +39,7 @@ for i in range(n + 1):
     inp = {"bboxes": [[int(v[0]) / W, int(v[1]) / H, int(v[2]) / W, int(v[3]) / H] for v in boxes.tolist()], "scores": d["scores"]}
     t0 = time.perf_counter(); fin = BF.process_json_with_sketch_NMS(str(out / "input.png"), "", inp, 0.2, cleaned_masks=cleaned); tick("sketch NMS (GPU pair table)", t0)
     t0 = time.perf_counter(); depth = DS.get_depth_map(str(out / "input.png")); tick("depth (GPU)", t0)
-    from inklayer_amd import refine_host as R
+    from oracle import refine4_ref as R
     rgb = np.asarray(pil)
     t0 = time.perf_counter()
     bx = R.unnormalize_bboxes(fin["bboxes"], H, W)
