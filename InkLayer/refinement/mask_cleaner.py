@@ -60,7 +60,7 @@ def run_clean_masks_on_sketch_dir(sketch_dir, masks=None, cleaned=None):
         cleaned = clean_masks_in_memory(masks)
     if hasattr(cleaned, "cpu"):
         cleaned = cleaned.cpu().numpy()
-    for i, m in enumerate(cleaned):
-        Image.fromarray(m, "L").save(os.path.join(dst, f"mask_{i}.png"))
+    from InkLayer.utils.io import save_all
+    save_all((Image.fromarray(m, "L"), os.path.join(dst, f"mask_{i}.png")) for i, m in enumerate(cleaned))
     print(f"cleaned {len(cleaned)} masks -> {dst}")
     return dst

@@ -114,14 +114,14 @@ def run_refinement_on_sketch_dir(sketch_dir, bboxes_path, out_base_dir=None, cle
     dis_dir = f"{out_base_dir}/masks_disjoint"
     shutil.rmtree(dis_dir, ignore_errors=True)
     os.makedirs(dis_dir, exist_ok=True)
-    for i, m in enumerate(res.disjoint_masks()):
-        Image.fromarray(m.astype(np.uint8) * 255, "L").save(f"{dis_dir}/mask_{i}.png")
+    from InkLayer.utils.io import save_all
+    save_all((Image.fromarray(m.astype(np.uint8) * 255, "L"), f"{dis_dir}/mask_{i}.png") for i, m in enumerate(res.disjoint_masks()))
     out_dir = f"{out_base_dir}/masks_final"
     shutil.rmtree(out_dir, ignore_errors=True)
     os.makedirs(out_dir, exist_ok=True)
     final_masks = res.final_masks()
-    for i, m in enumerate(final_masks):
-        Image.fromarray((np.asarray(m) > 0).astype(np.uint8) * 255, "L").save(f"{out_dir}/mask_{i}.png")
+    save_all((Image.fromarray((np.asarray(m) > 0).astype(np.uint8) * 255, "L"), f"{out_dir}/mask_{i}.png")
+             for i, m in enumerate(final_masks))
     depth_map = depth_dev.cpu().numpy()
     lo, hi = float(depth_map.min()), float(depth_map.max())             # cv2.normalize(NORM_MINMAX, 0..255)
     norm = (depth_map - lo) * (255.0 / (hi - lo)) if hi > lo else np.zeros_like(depth_map)

@@ -10,6 +10,7 @@ from PIL import Image, ImageDraw
 
 from InkLayer.detector.gdino import run_ft_dino_on_sketch
 from InkLayer.segmentor.sam import run_SAM
+from InkLayer.utils.io import save_all
 from InkLayer.utils.processing import process_dino_output, save_norm_bboxes
 
 
@@ -33,7 +34,8 @@ def _colour_by_masks(input_pil, masks_pils):
     return Image.fromarray(out.clip(0, 255).astype("uint8"))
 
 
-def run_inklayer_pipeline(input_path, out_base_dir, no_intermediate=False, inpaint=False):
+def _prepare_out_dir(input_path, out_base_dir):
+    """runner.py:22-29: <out_base_dir>/<basename before the first dot>, wiped if it has content, input.png saved."""
     input_name = os.path.basename(input_path).split(".")[0]
     input_pil = Image.open(input_path).convert("RGB")
     out_dir = os.path.join(out_base_dir, input_name)
@@ -41,25 +43,23 @@ def run_inklayer_pipeline(input_path, out_base_dir, no_intermediate=False, inpai
         shutil.rmtree(out_dir)                                   # reference: `rm -r`
     os.makedirs(out_dir, exist_ok=True)
     input_pil.save(os.path.join(out_dir, "input.png"))
+    return out_dir, input_pil
 
-    # detector -> boxes (runner.py:34-44): JSON gets the int()-truncated pixel boxes, SAM the float ones
-    dino_out = run_ft_dino_on_sketch(sketch_path=input_path)
-    boxes_tensor, phrases = process_dino_output(dino_out, input_pil)
+
+def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_intermediate=False, inpaint=False):
+    """Everything of run_inklayer_pipeline after the detector and the segmentor have answered (runner.py:35-101): the
+    output tree of the detection stage, then the refinement stage.  Shared by the per-file entry point below and by the
+    batched directory runner (inklayer_amd/batch_runner.py), so both write the same tree."""
     boxes_int = [[int(v) for v in box] for box in boxes_tensor.tolist()]
     save_norm_bboxes(bboxes_list=boxes_int, scores_list=dino_out["scores"], input_pil=input_pil,
                      out_path=os.path.join(out_dir, "bboxes.json"))
-
-    # segmentor -> masks (runner.py:49-64)
-    input_pil = Image.open(input_path).convert("RGB")
-    masks_np = run_SAM(image_pil=input_pil, boxes_filt=boxes_tensor)
     masks_pils = [Image.fromarray(m) for m in masks_np]
     masks_dir = os.path.join(out_dir, "masks")
     os.makedirs(masks_dir, exist_ok=True)
-    for i, m in enumerate(masks_pils):
-        m.save(os.path.join(masks_dir, f"mask_{i}.png"))         # PIL mode "1"
-    _colour_by_masks(input_pil, masks_pils).save(os.path.join(out_dir, "segmented_sketch.png"))
-    _draw_boxes(input_pil, boxes_int).save(os.path.join(out_dir, "bboxes.png"))
-    input_pil.save(os.path.join(out_dir, "input.png"))
+    save_all([(m, os.path.join(masks_dir, f"mask_{i}.png")) for i, m in enumerate(masks_pils)]       # PIL mode "1"
+              + [(_colour_by_masks(input_pil, masks_pils), os.path.join(out_dir, "segmented_sketch.png")),
+                 (_draw_boxes(input_pil, boxes_int), os.path.join(out_dir, "bboxes.png")),
+                 (input_pil, os.path.join(out_dir, "input.png"))])
 
     # Refinement (runner.py:69-73).  Mask cleanup, sketch NMS, Depth-Anything-V2 and the refinement stage (depth order,
     # disjoint parsing, growth, unlabeled mask) run on the GPU with the cleaned masks staying IN HBM from stage to stage
@@ -88,6 +88,17 @@ def run_inklayer_pipeline(input_path, out_base_dir, no_intermediate=False, inpai
             path = os.path.join(out_dir, item)
             shutil.rmtree(path) if os.path.isdir(path) else os.remove(path)
     return out_dir
+
+
+def run_inklayer_pipeline(input_path, out_base_dir, no_intermediate=False, inpaint=False):
+    out_dir, input_pil = _prepare_out_dir(input_path, out_base_dir)
+    # detector -> boxes (runner.py:34-44): JSON gets the int()-truncated pixel boxes, SAM the float ones
+    dino_out = run_ft_dino_on_sketch(sketch_path=input_path)
+    boxes_tensor, phrases = process_dino_output(dino_out, input_pil)
+    # segmentor -> masks (runner.py:49-64)
+    input_pil = Image.open(input_path).convert("RGB")
+    masks_np = run_SAM(image_pil=input_pil, boxes_filt=boxes_tensor)
+    return finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_intermediate, inpaint)
 
 
 def run_inpaint_single_layer(request_data, cur_dir, out_dir):

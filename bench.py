@@ -150,6 +150,39 @@ def cpu_baseline(n_boxes):
                       f"4 x global; mask decoder + postprocess on 4 boxes ({T['decoder4']:.2f} s) scaled to {n_boxes}"}
 
 
+def runner_leg(pipe, batch, n_boxes):
+    """Secondary figure (BASELINE config 5, not the metric): the WHOLE runner - the batched hot path plus mask cleanup,
+    sketch NMS, Depth-Anything-V2 ViT-B, the refinement stage and the reference's complete output tree of PNG / JSON
+    files per sketch - over a directory of `batch` synthetic 1024x1024 sketch PNGs (inklayer_amd/batch_runner.py, what
+    tools/run_dir.py runs per rank).  One warm-up pass, one timed pass; random weights, so the n best boxes per sketch
+    are kept instead of the 0.2 threshold."""
+    import shutil
+    import tempfile
+    from PIL import Image
+    from inklayer_amd import batch_runner, synthetic
+    os.environ["INKLAYER_RANDOM_WEIGHTS"] = "1"            # the depth plugin's singleton: no checkpoints exist offline
+    tmp = Path(tempfile.mkdtemp(prefix="ink_runner_"))
+    try:
+        (tmp / "in").mkdir()
+        for i in range(batch):
+            Image.fromarray(synthetic.synthetic_sketch(100 + i)).save(tmp / "in" / f"s{i}.png")
+        files = sorted(str(p) for p in (tmp / "in").glob("*.png"))
+        batch_runner.run_files(files[:2], str(tmp / "warm"), batch=batch, pipe=pipe, top_n=n_boxes)
+        stages = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = batch_runner.run_files(files, str(tmp / "out"), batch=batch, pipe=pipe, top_n=n_boxes, stage_s=stages)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_files = sum(len(list(Path(o).rglob("*.*"))) for o in outs)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"value": len(files) / dt, "unit": "sketches/s", "sketches": len(files), "seconds": dt,
+            "files_written": n_files, "stage_ms_per_sketch": {k: v / len(files) * 1e3 for k, v in stages.items()},
+            "note": "whole runner incl. Depth-Anything-V2, refinement and the reference's output tree on disk "
+                    "(PNG encoding on 8 host threads); one GPU, not the metric"}
+
+
 ATTN_ALGO_BYTES = lambda rows, width: 4.0 * rows * width * 2      # read q, k, v + write o once, f16 (SURVEY §8d)
 PEAK_HBM_TBS = 8.0
 
@@ -188,6 +221,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="sketches per GPU per step")
     ap.add_argument("--boxes", type=int, default=16, help="boxes per sketch (top-n by score)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-runner", action="store_true", help="skip the secondary whole-runner (config 5) measurement")
     args = ap.parse_args()
 
     from inklayer_amd import dist as idist
@@ -320,6 +354,8 @@ def main():
                          "end_to_end_tflops": FLOP_PER_SKETCH * sketches / dt / 1e12 / world},
             "attention": attention_summary(atrace, roof_steps),
         }
+        if world == 1 and not args.no_runner:
+            out["runner"] = runner_leg(pipe, args.batch, args.boxes)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.boxes)
         print(json.dumps(out), flush=True)

@@ -19,6 +19,7 @@ Bit-exact with the reference's own committed outputs (tests/test_refine_stage_gp
 from __future__ import annotations
 
 import ctypes as C
+import time
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -247,8 +248,11 @@ def refine_masks(cleaned_masks: torch.Tensor, boxes_px: Sequence[Sequence[int]],
                                    pair.data_ptr() if n else None, per.data_ptr() if n else None,
                                    scratch[1:].data_ptr(), st), "ink_refine_pair_tables")
     scores: List[float] = []
+    host_s = {}
     if order is None and n:
+        t0 = time.perf_counter()
         pts = sparse_sketch_sample(sketch_rgb)
+        host_s["stroke thinning (C++)"] = time.perf_counter() - t0
         if len(pts):
             assert depth is not None and depth.dtype == F32 and tuple(depth.shape) == (H, W) and depth.is_contiguous()
             pts_dev = torch.from_numpy(pts).to(dev)
@@ -303,15 +307,16 @@ def refine_masks(cleaned_masks: torch.Tensor, boxes_px: Sequence[Sequence[int]],
     disjoint = torch.empty_like(label)
     check(L.ink_refine_relabel_clean(label.data_ptr(), lut_dev.data_ptr(), H, W, disjoint.data_ptr(), st),
           "ink_refine_relabel_clean")
-    res = RefineResult(order, [float(s) for s in scores], sorted_boxes, disjoint.cpu().numpy(), n_dis, info)
+    res = RefineResult(order, [float(s) for s in scores], sorted_boxes, disjoint.cpu().numpy(), n_dis, info, timings=host_s)
     if stop_after_disjoint:
         return res
-    res.final, res.extra = grow_and_assign(disjoint, n_dis, sorted_boxes, sk)
+    res.final, res.extra = grow_and_assign(disjoint, n_dis, sorted_boxes, sk, host_s)
     return res
 
 
 @torch.no_grad()
-def grow_and_assign(disjoint: torch.Tensor, n_masks: int, boxes: Sequence[Sequence[int]], sk: torch.Tensor):
+def grow_and_assign(disjoint: torch.Tensor, n_masks: int, boxes: Sequence[Sequence[int]], sk: torch.Tensor,
+                    host_s: Optional[dict] = None):
     """improve_sam_masks (refiner.py:340-372) on a label image: growth, raster-order box assignment, the unlabeled extra
     mask.  disjoint: uint8 [H, W] on the GPU; sk: the 4 sketch planes.  -> (final label image np uint8, extra or None)."""
     L = _lib.lib()
@@ -364,7 +369,12 @@ def grow_and_assign(disjoint: torch.Tensor, n_masks: int, boxes: Sequence[Sequen
             check(L.ink_refine_query_dists(grown.data_ptr(), unl.data_ptr(), cand_dev.data_ptr(), Q, H, W, d2.data_ptr(), st),
                   "ink_refine_query_dists")
             nonempty = np.array([mb is not None for mb in mask_boxes], np.uint8)
-            lab = assign_unlabeled(q, barr, box2mask, d2.cpu().numpy(), nonempty, n_masks)
+            d2_h = d2.cpu().numpy()
+            t0 = time.perf_counter()
+            lab = assign_unlabeled(q, barr, box2mask, d2_h, nonempty, n_masks)
+            if host_s is not None:
+                host_s["raster-order assignment (C++)"] = time.perf_counter() - t0
+                host_s["unlabeled pixels"] = Q
             keep = lab > 0
             assign = np.concatenate([q[keep], lab[keep, None]], 1).astype(np.int32)
     extra = torch.empty((H, Wp), device=dev, dtype=I64)

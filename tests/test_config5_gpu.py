@@ -1,0 +1,78 @@
+"""BASELINE config 5 on the HIP path: a generated directory of mixed-size sketch PNGs through the batched directory
+runner (inklayer_amd/batch_runner.py: B files per pass of the hot path, then cleanup / NMS / depth / refinement per file)
+against the per-file entry point `InkLayer.runner.run_inklayer_pipeline` (what the reference's `main.py --dir` loops
+over, main.py:27-32): the same output trees, file for file.  Full-depth models, seeded random weights.  GPU box only."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@torch.no_grad()
+def test_directory_run_batched_equals_per_file_runner(dev, tmp_path, monkeypatch):
+    from PIL import Image
+    monkeypatch.setenv("INKLAYER_RANDOM_WEIGHTS", "1")
+    import InkLayer.detector.gdino as DET
+    import InkLayer.segmentor.sam as SEG
+    import InkLayer.refinement.depth_sort as DS
+    import InkLayer.runner as R
+    from inklayer_amd import batch_runner, synthetic
+    DET.model = None
+    SEG._engine = None
+    eng = DET.get_model()
+    eng.w["dec.norm.w"].mul_(0.05)                # un-saturate the random-weight scores ...
+    eng.w["dec.norm.b"].mul_(0.05)
+    eng._graphs.clear()
+    src = tmp_path / "sketches"
+    src.mkdir()
+    sizes = [(750, 750), (512, 640), (750, 750)]
+    for i, (h, w) in enumerate(sizes):
+        Image.fromarray(synthetic.synthetic_sketch(30 + i, h, w)).save(src / f"s{i}.png")
+    files = sorted(str(p) for p in src.glob("*.png"))
+    # ... and pick a threshold that keeps a handful of boxes on every sketch
+    from inklayer_amd import gdino, ops
+    thr = 0.0
+    for f in files:
+        rgb = np.asarray(Image.open(f).convert("RGB"))
+        oh, ow = gdino.resize_shape(rgb.shape[1], rgb.shape[0])
+        lg, _ = eng.forward([ops.resize_bilinear_u8(torch.from_numpy(np.ascontiguousarray(rgb)).to(dev), oh, ow)])
+        sc = torch.sort(lg[0].sigmoid().max(-1)[0], descending=True)[0]
+        thr = max(thr, float((sc[5] + sc[6]) / 2))
+    saved = eng.cfg.box_threshold
+    eng.cfg.box_threshold = thr
+    try:
+        stages = {}
+        outs = batch_runner.run_files(files, str(tmp_path / "batched"), batch=8, stage_s=stages)
+        solo = [R.run_inklayer_pipeline(f, str(tmp_path / "solo")) for f in files]
+    finally:
+        eng.cfg.box_threshold = saved
+    print("stages (s):", {k: round(v, 3) for k, v in stages.items()})
+    for o, s_, (h, w) in zip(outs, solo, sizes):
+        o, s_ = Path(o), Path(s_)
+        assert sorted(p.name for p in o.iterdir()) == sorted(p.name for p in s_.iterdir())
+        a, b = json.loads((o / "bboxes.json").read_text()), json.loads((s_ / "bboxes.json").read_text())
+        assert len(a["bboxes"]) == len(b["bboxes"]) >= 1
+        assert np.allclose(a["bboxes"], b["bboxes"], atol=1e-5) and np.allclose(a["scores"], b["scores"], atol=1e-5)
+        same_boxes = a == b
+        assert json.loads((o / "bboxes_final.json").read_text())["kept_indices"] == \
+            json.loads((s_ / "bboxes_final.json").read_text())["kept_indices"]
+        for sub in ("masks", "masks_cleaned", "masks_disjoint", "masks_final"):
+            fa, fb = sorted((o / sub).iterdir()), sorted((s_ / sub).iterdir())
+            assert [p.name for p in fa] == [p.name for p in fb], sub
+            for x, y in zip(fa, fb):
+                ia, ib = np.asarray(Image.open(x)) > 0, np.asarray(Image.open(y)) > 0
+                assert ia.shape == (h, w)
+                if same_boxes:
+                    assert np.array_equal(ia, ib), f"{sub}/{x.name} differs between the batched and the per-file run"
+                else:
+                    assert (ia & ib).sum() / max(1, (ia | ib).sum()) > 0.999
+        print(o.name, "boxes", len(a["bboxes"]), "bit-identical boxes:", same_boxes,
+              "final masks", len(list((o / "masks_final").iterdir())))
+    DS._engine = None
+    DET.model = None
+    SEG._engine = None
+    torch.cuda.empty_cache()
