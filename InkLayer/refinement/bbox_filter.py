@@ -54,6 +54,7 @@ def run_postprocess_boxes_on_sketch_dir(sketch_dir, sketch_iou_thresh=0.5, clean
     pen, (W, H) = ImageDraw.Draw(canvas), canvas.size
     for x1, y1, x2, y2 in kept["bboxes"]:
         pen.rectangle([x1 * W, y1 * H, x2 * W, y2 * H], outline=(220, 40, 40), width=2)
-    canvas.save(os.path.join(sketch_dir, "bboxes_final.png"))
+    from InkLayer.utils.io import save_all
+    save_all([(canvas, os.path.join(sketch_dir, "bboxes_final.png"))])
     print(f"sketch NMS kept {len(kept['bboxes'])} of {len(detections['bboxes'])} boxes -> {target}")
     return target

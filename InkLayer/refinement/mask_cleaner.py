@@ -34,6 +34,15 @@ def clean_masks_on_device(masks):
     return out
 
 
+def clean_device_masks(masks01_u8):
+    """The segmentor's 0/1 uint8 masks [n, H, W], still on the GPU -> cleaned 0 / 255 CUDA tensor (overflow checked)."""
+    from inklayer_amd import _lib, refine
+    out = refine.clean_segmentor_masks(masks01_u8.contiguous())
+    if int(out._ink_overflow_flag.item()) != 0:
+        raise _lib.InkLayerHipError("ink_mask_cleanup: a row has more runs than the closing bound allows (workspace overflow)")
+    return out
+
+
 def clean_masks_in_memory(masks):
     """-> cleaned uint8 [n, H, W] (0 / 255) numpy, computed on the GPU."""
     dev = clean_masks_on_device(masks)
@@ -61,6 +70,6 @@ def run_clean_masks_on_sketch_dir(sketch_dir, masks=None, cleaned=None):
     if hasattr(cleaned, "cpu"):
         cleaned = cleaned.cpu().numpy()
     from InkLayer.utils.io import save_all
-    save_all((Image.fromarray(m, "L"), os.path.join(dst, f"mask_{i}.png")) for i, m in enumerate(cleaned))
+    save_all((np.ascontiguousarray(m), os.path.join(dst, f"mask_{i}.png")) for i, m in enumerate(cleaned))
     print(f"cleaned {len(cleaned)} masks -> {dst}")
     return dst

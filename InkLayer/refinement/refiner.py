@@ -51,14 +51,8 @@ def match_masks_to_boxes(masks, boxes):
 
 
 def _colour(rgb, masks):
-    base = rgb.astype("float32")
-    out = base.copy()
-    for i, m in enumerate(masks):
-        hue = (i * 0.61803398875) % 1.0
-        col = 255.0 * np.array([0.6 + 0.4 * abs(((hue * 6 + k) % 6) / 3 - 1) for k in (0, 4, 2)], dtype="float32")
-        sel = np.asarray(m) > 0
-        out[sel] = 0.5 * base[sel] + 0.5 * col
-    return Image.fromarray(out.clip(0, 255).astype("uint8"))
+    from InkLayer.runner import colour_by_masks
+    return Image.fromarray(colour_by_masks(rgb, masks))
 
 
 def improve_sam_masks(sketch_image_path, masks_np, bboxes):
@@ -115,17 +109,17 @@ def run_refinement_on_sketch_dir(sketch_dir, bboxes_path, out_base_dir=None, cle
     shutil.rmtree(dis_dir, ignore_errors=True)
     os.makedirs(dis_dir, exist_ok=True)
     from InkLayer.utils.io import save_all
-    save_all((Image.fromarray(m.astype(np.uint8) * 255, "L"), f"{dis_dir}/mask_{i}.png") for i, m in enumerate(res.disjoint_masks()))
+    save_all((m.astype(np.uint8) * 255, f"{dis_dir}/mask_{i}.png") for i, m in enumerate(res.disjoint_masks()))
     out_dir = f"{out_base_dir}/masks_final"
     shutil.rmtree(out_dir, ignore_errors=True)
     os.makedirs(out_dir, exist_ok=True)
     final_masks = res.final_masks()
-    save_all((Image.fromarray((np.asarray(m) > 0).astype(np.uint8) * 255, "L"), f"{out_dir}/mask_{i}.png")
-             for i, m in enumerate(final_masks))
+    save_all(((np.asarray(m) > 0).astype(np.uint8) * 255, f"{out_dir}/mask_{i}.png") for i, m in enumerate(final_masks))
     depth_map = depth_dev.cpu().numpy()
     lo, hi = float(depth_map.min()), float(depth_map.max())             # cv2.normalize(NORM_MINMAX, 0..255)
     norm = (depth_map - lo) * (255.0 / (hi - lo)) if hi > lo else np.zeros_like(depth_map)
-    Image.fromarray(np.clip(norm, 0, 255).astype(np.uint8)).convert("RGB").save(f"{out_base_dir}/depth_map.png")
-    _colour(rgb, final_masks).save(f"{out_base_dir}/segmented_sketch_final.png")
+    from InkLayer.runner import colour_by_masks
+    save_all([(np.repeat(np.clip(norm, 0, 255).astype(np.uint8)[..., None], 3, axis=2), f"{out_base_dir}/depth_map.png"),
+              (colour_by_masks(rgb, final_masks), f"{out_base_dir}/segmented_sketch_final.png")])
     print(f"Results saved to {out_dir}")
     return out_dir

@@ -22,16 +22,22 @@ def _draw_boxes(input_pil, boxes):
     return im
 
 
-def _colour_by_masks(input_pil, masks_pils):
+def colour_by_masks(rgb, masks):
+    """A plain visualisation (InkLayer/utils/visualization.py is outside the hot path): every mask tints its pixels
+    half / half with its own colour, later masks on top.  One label image + one table look-up in uint8 instead of a
+    float pass over the image per mask.  rgb: uint8 [H, W, 3]; masks: sequence of [H, W] arrays (non-zero = inside)."""
     import numpy as np
-    base = np.asarray(input_pil).astype("float32")
-    out = base.copy()
-    for i, m in enumerate(masks_pils):
+    base = np.asarray(rgb)
+    label = np.zeros(base.shape[:2], np.uint16)
+    half = np.zeros((len(masks) + 1, 3), np.uint8)
+    for i, m in enumerate(masks):
         hue = (i * 0.61803398875) % 1.0
-        col = 255.0 * np.array([0.6 + 0.4 * abs(((hue * 6 + k) % 6) / 3 - 1) for k in (0, 4, 2)], dtype="float32")
-        sel = np.asarray(m, dtype=bool)
-        out[sel] = 0.5 * base[sel] + 0.5 * col
-    return Image.fromarray(out.clip(0, 255).astype("uint8"))
+        half[i + 1] = [int(127.5 * (0.6 + 0.4 * abs(((hue * 6 + k) % 6) / 3 - 1))) for k in (0, 4, 2)]
+        label[np.asarray(m) != 0] = i + 1
+    out = base.copy()
+    sel = label > 0
+    out[sel] = (base[sel] >> 1) + half[label[sel]]
+    return out
 
 
 def _prepare_out_dir(input_path, out_base_dir):
@@ -42,24 +48,26 @@ def _prepare_out_dir(input_path, out_base_dir):
     if os.path.exists(out_dir) and len(os.listdir(out_dir)) > 0:
         shutil.rmtree(out_dir)                                   # reference: `rm -r`
     os.makedirs(out_dir, exist_ok=True)
-    input_pil.save(os.path.join(out_dir, "input.png"))
+    save_all([(input_pil, os.path.join(out_dir, "input.png"))])
     return out_dir, input_pil
 
 
-def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_intermediate=False, inpaint=False):
+def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_intermediate=False, inpaint=False,
+                  masks_dev=None):
     """Everything of run_inklayer_pipeline after the detector and the segmentor have answered (runner.py:35-101): the
     output tree of the detection stage, then the refinement stage.  Shared by the per-file entry point below and by the
-    batched directory runner (inklayer_amd/batch_runner.py), so both write the same tree."""
+    batched directory runner (inklayer_amd/batch_runner.py), so both write the same tree.  masks_dev (optional): the same
+    masks as a uint8 0/1 [n, H, W] CUDA tensor when the caller still has them in HBM (saves the re-upload)."""
     boxes_int = [[int(v) for v in box] for box in boxes_tensor.tolist()]
     save_norm_bboxes(bboxes_list=boxes_int, scores_list=dino_out["scores"], input_pil=input_pil,
                      out_path=os.path.join(out_dir, "bboxes.json"))
-    masks_pils = [Image.fromarray(m) for m in masks_np]
+    import numpy as np
     masks_dir = os.path.join(out_dir, "masks")
     os.makedirs(masks_dir, exist_ok=True)
-    save_all([(m, os.path.join(masks_dir, f"mask_{i}.png")) for i, m in enumerate(masks_pils)]       # PIL mode "1"
-              + [(_colour_by_masks(input_pil, masks_pils), os.path.join(out_dir, "segmented_sketch.png")),
-                 (_draw_boxes(input_pil, boxes_int), os.path.join(out_dir, "bboxes.png")),
-                 (input_pil, os.path.join(out_dir, "input.png"))])
+    rgb = np.asarray(input_pil)
+    save_all([(np.asarray(m, dtype=bool), os.path.join(masks_dir, f"mask_{i}.png")) for i, m in enumerate(masks_np)]  # 1-bit, PIL mode "1"
+             + [(colour_by_masks(rgb, masks_np), os.path.join(out_dir, "segmented_sketch.png")),
+                (_draw_boxes(input_pil, boxes_int), os.path.join(out_dir, "bboxes.png"))])
 
     # Refinement (runner.py:69-73).  Mask cleanup, sketch NMS, Depth-Anything-V2 and the refinement stage (depth order,
     # disjoint parsing, growth, unlabeled mask) run on the GPU with the cleaned masks staying IN HBM from stage to stage
@@ -67,7 +75,11 @@ def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_inter
     # output tree); only the stroke thinning and the raster-order box assignment are host code (inklayer_amd/refine_stage.py).
     from InkLayer.refinement.mask_cleaner import run_clean_masks_on_sketch_dir, clean_masks_on_device
     from InkLayer.refinement.bbox_filter import run_postprocess_boxes_on_sketch_dir
-    cleaned = clean_masks_on_device(masks_np)
+    if masks_dev is not None and len(masks_np):
+        from InkLayer.refinement.mask_cleaner import clean_device_masks
+        cleaned = clean_device_masks(masks_dev)
+    else:
+        cleaned = clean_masks_on_device(masks_np)
     if cleaned is None:
         import numpy as _np
         cleaned = _np.zeros((0,) + input_pil.size[::-1], _np.uint8)

@@ -60,6 +60,6 @@ def run_files(files: Sequence[str], out_base_dir: str, batch: int = 8, no_interm
             dino_out = {"bboxes": r.boxes_xyxy_norm.tolist(), "scores": r.scores.tolist(),
                         "labels": ["object"] * len(r.scores)}
             outs.append(R.finish_sketch(out_dir, pil, dino_out, r.boxes_pixel, [m[k] for k in range(m.shape[0])],
-                                        no_intermediate=no_intermediate))
+                                        no_intermediate=no_intermediate, masks_dev=r.masks))
         tick("tree + refinement (per file)", t0)
     return outs
