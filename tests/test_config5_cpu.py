@@ -42,6 +42,7 @@ FAKES = textwrap.dedent('''
     def install():
         batch_runner._pipeline = lambda: FakePipe()
         MC.clean_masks_on_device = lambda masks: np.stack([np.asarray(m, dtype=np.uint8) * 255 for m in masks])
+        MC.clean_device_masks = lambda m: m.numpy() * 255
         BF.process_json_with_sketch_NMS = lambda sp, md, d, iou_threshold=0.2, cleaned_masks=None: {
             "bboxes": d["bboxes"][:1], "scores": d["scores"][:1], "kept_indices": [0], "threshold": iou_threshold}
         RF.get_depth_map_device = lambda path: torch.from_numpy(np.tile(
@@ -81,7 +82,7 @@ def restore_plugins():
     import InkLayer.refinement.bbox_filter as BF
     import InkLayer.refinement.refiner as RF
     from inklayer_amd import batch_runner, refine_stage
-    saved = [(m, k, getattr(m, k)) for m, k in ((batch_runner, "_pipeline"), (MC, "clean_masks_on_device"),
+    saved = [(m, k, getattr(m, k)) for m, k in ((batch_runner, "_pipeline"), (MC, "clean_masks_on_device"), (MC, "clean_device_masks"),
                                                 (BF, "process_json_with_sketch_NMS"), (RF, "get_depth_map_device"),
                                                 (RF, "_stack_on_gpu"), (refine_stage, "refine_masks"),
                                                 (R, "run_ft_dino_on_sketch"), (R, "run_SAM"))]
