@@ -53,7 +53,20 @@ typedef struct InkGemm {
   int32_t M, N, K;
   int32_t lda, ldw, ldr, ldc;
   int32_t act;              /* 0 none, 1 GELU(erf), 2 ReLU */
-  int32_t c_f16;            /* 0: C is f32, 1: C is f16 */
+  int32_t c_f16;            /* 0: C is f32, 1: C is f16, 2: split f16 - C = hi plane, C_lo = lo plane, value = hi + lo */
+  /* ABI 4: the residual stream as two f16 planes + LayerNorm folded into the consuming projection (SAM ViT-H blocks,
+   * SA/modeling/image_encoder.py:166-182: x = x + attn(norm1(x)); x = x + mlp(norm2(x))) */
+  void* C_lo;               /* c_f16 == 2: f16 [*, ldc], lo = f16(v - f16(v)) */
+  const void* res_hi;       /* split residual (instead of `residual`): f16 [*, ldr] planes, residual = hi + lo; */
+  const void* res_lo;       /*   only in the linear form (no activation, no col_scale) */
+  float* stats_out;         /* c_f16 == 2: [rows, stats_parts, 2] (sum, sum of squares) of every output row over each
+                               column chunk of ink_gemm_query_stats_chunk(M, N, K) columns; stats_parts = N / chunk */
+  const float* ln_stats;    /* folded LayerNorm over the rows of A: [M, ln_parts, 2] partial sums over the ln_dim source
+                               columns; then C = rstd_m * (A W^T - mean_m * ln_colsum) + bias (W carries gamma, bias
+                               carries beta W^T + b) before the activation */
+  const float* ln_colsum;   /* [N]: sum_k W[n, k] */
+  int32_t stats_parts, ln_parts, ln_dim;
+  float ln_eps;
 } InkGemm;
 #define INK_ACT_NONE 0
 #define INK_ACT_GELU 1
@@ -66,6 +79,7 @@ int ink_gemm_set_variant(int32_t v);
 /* Which tile variant the built-in heuristic picks for (M,N,K): 10 = 256x256x64 / 16 waves (the dominant kernel),
  * 0 = 128x128x64 / 4 waves, 32 = 128x128x32 (K % 64 != 0).  Pure host function, used by bench.py's roofline. */
 int ink_gemm_query_variant(int32_t M, int32_t N, int32_t K);
+int ink_gemm_query_stats_chunk(int32_t M, int32_t N, int32_t K);
 
 /* ------------------------------------------------------------------------
  * Row LayerNorm with optional row gather (fuses window-partition / pad /
@@ -339,6 +353,15 @@ int ink_mask_cleanup(const void* masks_u8, int32_t n, int32_t H, int32_t W, int3
  * sketch_rgb_u8: [H, W, 3] (the masks have the sketch's size on this path); bits_ws: uint64[n * ceil(H*W/64)]. */
 int ink_mask_sketch_iou_counts(const void* masks_u8, const void* sketch_rgb_u8, int32_t n, int32_t H, int32_t W,
                                void* bits_ws_u64, int32_t* counts, void* stream);
+
+/* The SAM ViT-H residual stream as two f16 planes (x = hi + lo, hi = f16(x), lo = f16(x - hi): ~22 significant bits),
+ * so that the hi plane IS the f16 operand of the next projection and LayerNorm folds into that projection
+ * (InkGemm.ln_stats; SA/modeling/image_encoder.py:166-182).
+ * ink_hilo_split_stats: f32 rows [rows, C] -> hi / lo planes (row stride ldo) + stats [rows, C / chunk, 2] = (sum, sum of
+ * squares) per chunk of `chunk` columns, the layout InkGemm.stats_out / ln_stats use.  ink_hilo_join: out = hi + lo. */
+int ink_hilo_split_stats(const float* x, int64_t ldx, int32_t rows, int32_t C, void* hi_f16, void* lo_f16, int64_t ldo,
+                         float* stats, int32_t chunk, void* stream);
+int ink_hilo_join(const void* hi_f16, const void* lo_f16, int64_t n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------
  * Refinement stage on resident masks: depth ordering support, disjoint parsing, mask growth, box

@@ -22,6 +22,9 @@ class InkGemm(C.Structure):
         ("M", c_int), ("N", c_int), ("K", c_int),
         ("lda", c_int), ("ldw", c_int), ("ldr", c_int), ("ldc", c_int),
         ("act", c_int), ("c_f16", c_int),
+        ("C_lo", c_void_p), ("res_hi", c_void_p), ("res_lo", c_void_p), ("stats_out", c_void_p),
+        ("ln_stats", c_void_p), ("ln_colsum", c_void_p),
+        ("stats_parts", c_int), ("ln_parts", c_int), ("ln_dim", c_int), ("ln_eps", c_float),
     ]
 
 
@@ -44,6 +47,9 @@ SIGNATURES = {
     "ink_gemm_f16": [C.POINTER(InkGemm), c_void_p],
     "ink_gemm_set_variant": [c_int],
     "ink_gemm_query_variant": [c_int, c_int, c_int],
+    "ink_gemm_query_stats_chunk": [c_int, c_int, c_int],
+    "ink_hilo_split_stats": [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p],
+    "ink_hilo_join": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p],
     "ink_layernorm_rows": [c_void_p, c_i64, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                            c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p, c_int, c_void_p],
     "ink_add_split_f16": [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p],

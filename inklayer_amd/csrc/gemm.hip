@@ -52,7 +52,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //     loaded before the first store;
 //   * the rare non-linear residual / layer-scale loads stay in the loop, each used inside its own branch.
 __device__ __forceinline__ bool residual_preloaded(const InkGemm& p) {
-  return p.residual && p.act == INK_ACT_NONE && !p.col_scale;
+  return (p.residual || p.res_hi) && p.act == INK_ACT_NONE && !p.col_scale;
 }
 
 // Output row of every accumulator row of the wave tile (lane & 15 = row within the 16-row slab), -1 = outside M or
@@ -69,11 +69,31 @@ __device__ __forceinline__ void wave_rows(int (&rows)[TM], const InkGemm& p, int
   }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool SPLIT = false>
 __device__ __forceinline__ void init_wave_tile(f32x4 (&acc)[TM][TN], const InkGemm& p, const int (&rows)[TM], int nw,
                                                int lane) {
   const int fq = lane >> 4;
   const bool pre = residual_preloaded(p);
+  if (SPLIT) {
+    // residual stream kept as two f16 planes (value = hi + lo, ~22 significant bits): the hi plane doubles as the
+    // f16 operand of the next projection, so no conversion pass ever reads the stream
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti) {
+      const int r = pre ? rows[ti] : -1;
+      const size_t off = (size_t)max(r, 0) * p.ldr + nw + fq * 4;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[ti][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (r >= 0 && nw + j * 16 + fq * 4 < p.N) {
+          const f16x4 h = *(const f16x4*)((const f16*)p.res_hi + off + j * 16);
+          const f16x4 l = *(const f16x4*)((const f16*)p.res_lo + off + j * 16);
+          acc[ti][j] = (f32x4){(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
+                               (float)h[3] + (float)l[3]};
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti) {
     const int r = pre ? rows[ti] : -1;
@@ -86,21 +106,61 @@ __device__ __forceinline__ void init_wave_tile(f32x4 (&acc)[TM][TN], const InkGe
   }
 }
 
+// LayerNorm fold: the A operand of the projection is the RAW residual stream (its f16 hi plane) and W
+// carries the norm's gamma, so  LN(x) W^T + b = rstd_m (acc_mn - mean_m s_n) + c_n  with s_n = sum_k W'[n,k] and
+// c_n = beta W^T + b (passed as the bias).  mean / rstd of the wave tile's rows come from the partial (sum, sum of
+// squares) the PRODUCER of the stream wrote next to it (stats_out of the previous projection): lane L reduces rows
+// L, L + 64, ... of the wave tile and parks (rstd, rstd * mean) in a wave-private LDS strip; the epilogue reads them
+// back per accumulator row.  Called before the K loop (its loads are ordinary loads: they must not sit between DMAs).
+template <int TM, int TN>
+__device__ __forceinline__ void ln_rows_prologue(const InkGemm& p, float2* strip, int mw, int nw, int lane) {
+  // columns of the wave tile: (colsum, bias) pairs behind the row strip - the epilogue then reads everything it needs
+  // from LDS (short latency, nothing to keep in registers across the K loop)
+  float2* cols = strip + TM * 16;
+  for (int c = lane; c < TN * 16; c += 64) {
+    const int n = nw + c;
+    cols[c] = n < p.N ? make_float2(p.ln_colsum[n], p.bias ? p.bias[n] : 0.f) : make_float2(0.f, 0.f);
+  }
+  for (int r = lane; r < TM * 16; r += 64) {
+    const int m = mw + r;
+    float2 o = make_float2(0.f, 0.f);
+    if (m < p.M) {
+      const float2* sp = (const float2*)p.ln_stats + (size_t)m * p.ln_parts;
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < p.ln_parts; ++k) {
+        const float2 v = sp[k];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+      }
+      const double mean = s1 / (double)p.ln_dim;
+      const double var = fmax(s2 / (double)p.ln_dim - mean * mean, 0.0);
+      const float rstd = (float)(1.0 / sqrt(var + (double)p.ln_eps));
+      o = make_float2(rstd, rstd * (float)mean);
+    }
+    strip[r] = o;
+  }
+}
+
 // Each 16-row slab goes through a wave-private LDS patch so that HBM sees whole row segments (16 B per lane,
 // 128 B (f16) / 256 B (f32) contiguous per row); bias / activation / layer-scale are applied on the way in.
 // MODE: -1 = activation / layer scale / late residual decided at run time (the generic kernels);  0, 1, 2 = compile-time
 // "no activation" / GELU / ReLU with no layer scale and no late residual - the ping-pong kernel dispatches on it ONCE per
 // workgroup, so that the 20 activations of a slab form one basic block (the per-group run-time branches cut the GELU
 // into 4-element dependent chains: transcendental latency instead of throughput).
-template <int TM, int TN, bool F16O, int MODE = -1>
+// OUT: 0 = f32 C, 1 = f16 C, 2 = split f16 (C = hi plane, C_lo = lo plane: hi = f16(v), lo = f16(v - hi)).
+// p.stats_out: per output row and per wave-tile column chunk the partial (sum, sum of squares) of the final values -
+// the LayerNorm statistics of the NEXT projection (ln_rows_prologue), computed here for free.
+// p.ln_stats: this projection is itself a folded LayerNorm + Linear (see ln_rows_prologue); `strip` holds its rows.
+template <int TM, int TN, int OUT, int MODE = -1, bool LNF = false>
 __device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkGemm& p, char* er,
-                                                const int (&rows)[TM], int nw, int lane) {
+                                                const int (&rows)[TM], int nw, int lane, const float2* strip = nullptr) {
+  constexpr bool F16O = OUT == 1;
   constexpr int WNC = TN * 16, EP = WNC * 4 + 16;
-  constexpr int ES = F16O ? 8 : 4;                 // elements per 16-B chunk of the output row
+  constexpr int ES = OUT == 0 ? 4 : 8;             // elements per 16-B chunk of the output row(s)
   constexpr int CPRW = WNC / ES;                   // chunks per patch row
   constexpr int NIT = (16 * CPRW + 63) / 64;       // chunk rounds per slab
   const int fr = lane & 15, fq = lane >> 4;
-  const bool wide16 = F16O && (p.ldc % 8 == 0);
+  const bool wide16 = OUT != 0 && (p.ldc % 8 == 0);
   const bool res_late = MODE < 0 && p.residual && !residual_preloaded(p);
   const int act = MODE < 0 ? p.act : MODE;
   const bool scaled = MODE < 0 && p.col_scale != nullptr;
@@ -113,18 +173,38 @@ __device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkG
     n_of[it] = nw + (c % CPRW) * ES;
   }
 
-  // the only load of the epilogue, before the first store: bias
+  // the only loads of the epilogue, before the first store: bias (and the column sums of a folded LayerNorm);
+  // LNF is a compile-time switch: a run-time branch around two versions of the accumulator update makes hipcc keep
+  // both copies of the array alive at the join (spills)
+  if (LNF) {
+    const float2* cols = strip + TM * 16;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = nw + j * 16 + fq * 4;
-    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+    for (int j = 0; j < TN; ++j) {
+      const f32x4 c01 = *(const f32x4*)(cols + j * 16 + fq * 4);       // (s, b) of columns 0, 1
+      const f32x4 c23 = *(const f32x4*)(cols + j * 16 + fq * 4 + 2);   // ... of columns 2, 3
+      const f32x4 sv = (f32x4){c01[0], c01[2], c23[0], c23[2]}, bv = (f32x4){c01[1], c01[3], c23[1], c23[3]};
 #pragma unroll
-    for (int ti = 0; ti < TM; ++ti) acc[ti][j] += bv;     // unconditional: no copy of the array at a join
+      for (int ti = 0; ti < TM; ++ti) {
+        const float2 mr = strip[ti * 16 + fr];               // (rstd, rstd * mean) of this accumulator row
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[ti][j][e] = fmaf(mr.x, acc[ti][j][e], fmaf(-mr.y, sv[e], bv[e]));
+      }
+      __builtin_amdgcn_sched_barrier(0);                       // one column group at a time: 8 + 16 live values
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nw + j * 16 + fq * 4;
+      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+      for (int ti = 0; ti < TM; ++ti) acc[ti][j] += bv;     // unconditional: no copy of the array at a join
+    }
   }
 
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti) {
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       f32x4 v = acc[ti][j];
@@ -139,11 +219,24 @@ __device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkG
         const int n = nw + j * 16 + fq * 4;
         if (n < p.N) v *= *(const f32x4*)(p.col_scale + n);
       }
+      if (OUT == 2 && nw + j * 16 + fq * 4 < p.N) {
+        s1 += (v[0] + v[1]) + (v[2] + v[3]);
+        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      }
       if (F16O) {
         *(f16x4*)(er + fr * EP + (j * 16 + fq * 4) * 2) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
       } else {
         *(f32x4*)(er + fr * EP + (j * 16 + fq * 4) * 4) = v;
       }
+    }
+    if (OUT == 2 && p.stats_out) {
+      // the four lanes fr, fr + 16, fr + 32, fr + 48 hold the columns of accumulator row fr
+      s1 += __shfl_xor(s1, 16, 64);
+      s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (fq == 0 && rows[ti] >= 0)
+        ((float2*)p.stats_out)[(size_t)rows[ti] * p.stats_parts + nw / WNC] = make_float2(s1, s2);
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -168,6 +261,29 @@ __device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkG
             *(f16x4*)dst = (f16x4){d[0], d[1], d[2], d[3]};
             if (c_n + 8 <= p.N) *(f16x4*)(dst + 4) = (f16x4){d[4], d[5], d[6], d[7]};
           }
+        } else if (OUT == 2) {
+          const f32x4 d0 = *(const f32x4*)src, d1 = *(const f32x4*)(src + 16);
+          f16x8 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            hi[e] = (f16)d0[e];
+            lo[e] = (f16)(d0[e] - (float)hi[e]);
+            hi[e + 4] = (f16)d1[e];
+            lo[e + 4] = (f16)(d1[e] - (float)hi[e + 4]);
+          }
+          f16* dh = (f16*)p.C + (size_t)r * p.ldc + c_n;
+          f16* dl = (f16*)p.C_lo + (size_t)r * p.ldc + c_n;
+          if (wide16 && c_n + 8 <= p.N) {
+            *(f16x8*)dh = hi;
+            *(f16x8*)dl = lo;
+          } else {
+            *(f16x4*)dh = (f16x4){hi[0], hi[1], hi[2], hi[3]};
+            *(f16x4*)dl = (f16x4){lo[0], lo[1], lo[2], lo[3]};
+            if (c_n + 8 <= p.N) {
+              *(f16x4*)(dh + 4) = (f16x4){hi[4], hi[5], hi[6], hi[7]};
+              *(f16x4*)(dl + 4) = (f16x4){lo[4], lo[5], lo[6], lo[7]};
+            }
+          }
         } else {
           f32x4 d = *(const f32x4*)src;
           if (res_late) d += *(const f32x4*)(p.residual + (size_t)r * p.ldr + c_n);
@@ -184,7 +300,9 @@ __device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkG
 // (cdna_hip_programming.md §5 "Pipelining across barriers"): the wait that retires tile kt comes
 // before the barrier, the reads of tile kt after it, and the buffer that is re-filled is the one read
 // in the previous iteration (every wave has passed this iteration's barrier, i.e. finished those reads).
-template <int BM, int BN, int BK, int WM, int WN, int NS, int ABL = 0>
+// EXT: the kernel also carries the ABI-4 forms (split-f16 output + row statistics, folded LayerNorm); only the 128x128
+// tiles are built with it - the 16-wave 256x256 tile has 128 VGPRs per lane and no room for them.
+template <int BM, int BN, int BK, int WM, int WN, int NS, int ABL = 0, bool EXT = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group_m) {
   constexpr int NT = WM * WN * 64;
   constexpr int CPR = BK / 8;          // 16-B chunks per tile row
@@ -254,6 +372,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
   int rows[TM];
   wave_rows<TM>(rows, p, m0 + wm * (BM / WM), lane);
   f32x4 acc[TM][TN];
+  // wave-private strip behind the staging buffers: (rstd, rstd * mean) of the wave tile's rows (folded LayerNorm)
+  float2* strip = (float2*)(smem + NS * STAGE) + wave * (TM * 16 + TN * 16);
+  if (EXT && p.ln_stats) ln_rows_prologue<TM, TN>(p, strip, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 
   const int fr = lane & 15, fq = lane >> 4;
   const int offA = (wm * (BM / WM) + fr) * ROWB;
@@ -286,7 +407,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
 
   if constexpr (NS == 2) {
     stage(0, 0);
-    init_wave_tile<TM, TN>(acc, p, rows, n0 + wn * (BN / WN), lane);
+    if (EXT && p.res_hi) {
+      init_wave_tile<TM, TN, true>(acc, p, rows, n0 + wn * (BN / WN), lane);
+    } else {
+      init_wave_tile<TM, TN>(acc, p, rows, n0 + wn * (BN / WN), lane);
+    }
     for (int kt = 0; kt < nk; ++kt) {
       // the LDS-DMA of tile kt is tracked by vmcnt only: drain it EXPLICITLY before the barrier (whether
       // __syncthreads() alone emits the vmcnt wait depends on what else the compiler sees in flight)
@@ -333,10 +458,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
   static_assert(WM * WN * 16 * EP <= NS * STAGE, "epilogue patch must fit in the staging LDS");
   __syncthreads();                             // every wave is done reading the last K-tile
   char* er = smem + wave * (16 * EP);
-  if (p.c_f16) {
-    store_wave_tile<TM, TN, true>(acc, p, er, rows, n0 + wn * WNC, lane);
+  if (EXT && p.ln_stats) {
+    if (p.c_f16 == 1) {
+      store_wave_tile<TM, TN, 1, -1, true>(acc, p, er, rows, n0 + wn * WNC, lane, strip);
+    } else {
+      store_wave_tile<TM, TN, 0, -1, true>(acc, p, er, rows, n0 + wn * WNC, lane, strip);
+    }
+  } else if (EXT && p.c_f16 == 2) {
+    store_wave_tile<TM, TN, 2>(acc, p, er, rows, n0 + wn * WNC, lane);
+  } else if (p.c_f16 == 1) {
+    store_wave_tile<TM, TN, 1>(acc, p, er, rows, n0 + wn * WNC, lane);
   } else {
-    store_wave_tile<TM, TN, false>(acc, p, er, rows, n0 + wn * WNC, lane);
+    store_wave_tile<TM, TN, 0>(acc, p, er, rows, n0 + wn * WNC, lane);
   }
 }
 
@@ -361,7 +494,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
 // the eight A fragments live: rows 4-7 are read DURING the MFMA slot into the registers of rows 0-3 as soon as
 // those have issued their MFMAs.  A granule is then still being read one slot later, so its ring slot may only be
 // refilled one granule later: the DMA runs RING-2 granules ahead instead of RING-1.
-template <int RING, int TN, int ABL = 0, bool LATE_A = (TN > 4)>
+// EPI: 0 = the epilogue is chosen at run time among the ABI-3 forms (bias / activation / layer scale / f32 residual,
+// f32 or f16 C); 1, 2, 3 = ONE compiled epilogue each for the SAM ViT-H block on the split-f16 residual stream:
+// 1 = folded LayerNorm -> f16 (qkv), 2 = folded LayerNorm + GELU -> f16 (lin1), 3 = split residual in, split C + row
+// statistics out (proj, lin2).  Separate kernels rather than more branches: with every form inside one kernel the
+// register allocator spilled around the dispatch.
+template <int RING, int TN, int ABL = 0, bool LATE_A = (TN > 4), int EPI = 0>
 __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   constexpr int BM = 256, BN = 64 * TN, BK = 32, NT = 512;
   constexpr int CPR = BK / 8, ROWB = BK * 2;
@@ -456,11 +594,13 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   // assume only DMA in flight), without one only granule 0 is waited for
   int rows[TM];
   wave_rows<TM>(rows, p, m0 + grp * 128, lane);
+  float2* strip = (float2*)(smem + RING * GRAN) + wave * (128 + WNC);   // behind the ring: rows + columns of the fold
 #pragma unroll
   for (int g = 0; g < AHEAD; ++g) dma(g, g);
+  if (EPI == 1 || EPI == 2) ln_rows_prologue<TM, TN>(p, strip, m0 + grp * 128, n0 + wn * WNC, lane);   // (drains the fill, like a preload)
   f32x4 acc[TM][TN];
-  init_wave_tile<TM, TN>(acc, p, rows, n0 + wn * WNC, lane);
-  if (residual_preloaded(p)) {
+  init_wave_tile<TM, TN, EPI == 3>(acc, p, rows, n0 + wn * WNC, lane);
+  if (residual_preloaded(p) || EPI == 1 || EPI == 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     wait_ahead(std::integral_constant<int, AHEAD - 1>{});
@@ -525,19 +665,25 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   char* er = smem + wave * (16 * EP);
   // (group_m < 0: A/B switch of tools/gemm_res_ab.py - take the run-time-dispatch epilogue everywhere)
   const bool plain = group_m > 0 && !p.col_scale && !(p.residual && !residual_preloaded(p));
-  if (p.c_f16) {
+  if constexpr (EPI == 1) {
+    store_wave_tile<TM, TN, 1, INK_ACT_NONE, true>(acc, p, er, rows, n0 + wn * WNC, lane, strip);
+  } else if constexpr (EPI == 2) {
+    store_wave_tile<TM, TN, 1, INK_ACT_GELU, true>(acc, p, er, rows, n0 + wn * WNC, lane, strip);
+  } else if constexpr (EPI == 3) {
+    store_wave_tile<TM, TN, 2, INK_ACT_NONE>(acc, p, er, rows, n0 + wn * WNC, lane);
+  } else if (p.c_f16) {
     if (plain && p.act == INK_ACT_GELU) {          // lin1 of the ViT-H MLP
-      store_wave_tile<TM, TN, true, INK_ACT_GELU>(acc, p, er, rows, n0 + wn * WNC, lane);
+      store_wave_tile<TM, TN, 1, INK_ACT_GELU>(acc, p, er, rows, n0 + wn * WNC, lane);
     } else if (plain && p.act == INK_ACT_NONE) {   // qkv
-      store_wave_tile<TM, TN, true, INK_ACT_NONE>(acc, p, er, rows, n0 + wn * WNC, lane);
+      store_wave_tile<TM, TN, 1, INK_ACT_NONE>(acc, p, er, rows, n0 + wn * WNC, lane);
     } else {
-      store_wave_tile<TM, TN, true>(acc, p, er, rows, n0 + wn * WNC, lane);
+      store_wave_tile<TM, TN, 1>(acc, p, er, rows, n0 + wn * WNC, lane);
     }
   } else {
     if (plain && p.act == INK_ACT_NONE) {          // proj, lin2 (residual preloaded into the accumulators)
-      store_wave_tile<TM, TN, false, INK_ACT_NONE>(acc, p, er, rows, n0 + wn * WNC, lane);
+      store_wave_tile<TM, TN, 0, INK_ACT_NONE>(acc, p, er, rows, n0 + wn * WNC, lane);
     } else {
-      store_wave_tile<TM, TN, false>(acc, p, er, rows, n0 + wn * WNC, lane);
+      store_wave_tile<TM, TN, 0>(acc, p, er, rows, n0 + wn * WNC, lane);
     }
   }
   if (ABL & 8) {
@@ -553,28 +699,31 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   }
 }
 
-template <int RING, int TN = 4, int ABL = 0, bool LATE_A = (TN > 4)>
+template <int RING, int TN = 4, int ABL = 0, bool LATE_A = (TN > 4), int EPI = 0>
 static int launch_gemm_pp(const InkGemm& p, hipStream_t s, int group_m) {
   if (p.K / 32 < RING) return 1;
+  if (EPI == 0 && (p.ln_stats || p.c_f16 == 2 || p.res_hi)) return INK_ERR_ARG;
   constexpr int BN = 64 * TN;
-  constexpr int lds = RING * (256 + BN) * 32 * 2;
+  constexpr int lds = RING * (256 + BN) * 32 * 2 + 8 * (128 + 16 * TN) * 8;   // ring + the LayerNorm-fold strips of the 8 waves
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt_pp<RING, TN, ABL, LATE_A>,
+  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt_pp<RING, TN, ABL, LATE_A, EPI>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)attr;
   const int ntiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_f16_nt_pp<RING, TN, ABL, LATE_A>), dim3(ntiles), dim3(512), lds, s, p, group_m);
+  hipLaunchKernelGGL((gemm_f16_nt_pp<RING, TN, ABL, LATE_A, EPI>), dim3(ntiles), dim3(512), lds, s, p, group_m);
   return ink_launch_status();
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, int ABL = 0>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int ABL = 0, bool EXT = false>
 static int launch_gemm(const InkGemm& p, hipStream_t s, int group_m = 1) {
-  constexpr int lds = NS * (BM + BN) * BK * 2;
-  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt<BM, BN, BK, WM, WN, NS, ABL>,
+  constexpr int lds = NS * (BM + BN) * BK * 2 + (EXT ? (BM * WN + BN * WM) * 8 : 0);   // staging (+ the LayerNorm-fold strips)
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  if (!EXT && (p.ln_stats || p.c_f16 == 2 || p.res_hi)) return INK_ERR_ARG;
+  static bool attr = ((void)hipFuncSetAttribute((const void*)gemm_f16_nt<BM, BN, BK, WM, WN, NS, ABL, EXT>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)attr;
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_f16_nt<BM, BN, BK, WM, WN, NS, ABL>), dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, p, group_m);
+  hipLaunchKernelGGL((gemm_f16_nt<BM, BN, BK, WM, WN, NS, ABL, EXT>), dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, p, group_m);
   return ink_launch_status();
 }
 
@@ -591,6 +740,11 @@ extern "C" int ink_gemm_query_variant(int32_t M, int32_t N, int32_t K) {
   const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   const bool n_fits = (N % 256 == 0) || N >= 1024;
   return (tiles256 >= 200 && n_fits) ? 10 : 0;
+}
+// columns per statistics chunk (= wave-tile width) of the kernel ink_gemm_f16 picks for this shape: what
+// InkGemm.stats_parts = N / chunk has to be computed from
+extern "C" int ink_gemm_query_stats_chunk(int32_t M, int32_t N, int32_t K) {
+  return (K % 64 == 0 && ink_gemm_query_variant(M, N, K) == 45) ? 80 : 64;
 }
 extern "C" int ink_abi_version(void) { return INK_ABI_VERSION; }
 extern "C" int ink_gemm_set_variant(int32_t v) {
@@ -621,16 +775,27 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
   INK_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0);
   INK_CHECK_ARG(((uintptr_t)p.C & 15) == 0);
   INK_CHECK_ARG(p.act >= 0 && p.act <= 2);
+  INK_CHECK_ARG(p.c_f16 >= 0 && p.c_f16 <= 2 && (p.c_f16 != 2 || (p.C_lo && ((uintptr_t)p.C_lo & 15) == 0)));
+  INK_CHECK_ARG(!p.res_hi || (p.res_lo && !p.residual && p.ldr % 4 == 0 && p.ldr >= p.N && p.act == INK_ACT_NONE &&
+                              !p.col_scale));
+  INK_CHECK_ARG(!p.ln_stats || (p.ln_colsum && p.ln_parts > 0 && p.ln_dim > 0 && !p.row_map));
   hipStream_t s = (hipStream_t)stream;
   int v = g_variant;           // -1 (default): shape heuristic.  No environment variable reaches this function.
   int gm = 1;
   bool generic_epilogue = false;
   if (v >= 10000) { generic_epilogue = true; v -= 10000; }
   if (v >= 100) { gm = v / 100; v = v % 100; }
-  if (p.K % 64 != 0) return launch_gemm<128, 128, 32, 2, 2, 2>(p, s);
+  const bool ext = p.ln_stats || p.c_f16 == 2 || p.res_hi;      // ABI-4 forms: ping-pong or 128x128 tiles only
+  if (p.K % 64 != 0) return launch_gemm<128, 128, 32, 2, 2, 2, 0, true>(p, s);
   if (v < 0) {
     v = ink_gemm_query_variant(p.M, p.N, p.K);
     gm = 4;
+    if (ext && v == 10) { v = 0; gm = 1; }
+  }
+  if (p.stats_out) {      // row statistics are per wave-tile chunk: the split output only, whole chunks only
+    const bool pp3 = v == 45 && !p.ln_stats && !p.col_scale && !p.row_map && p.res_hi && p.act == INK_ACT_NONE;
+    const int chunk = pp3 ? 80 : 64;
+    INK_CHECK_ARG(p.c_f16 == 2 && p.N % chunk == 0 && p.stats_parts == p.N / chunk && g_variant < 0);
   }
   // Production variants: 0 / 32 (128x128 tiles, K step 64 / 32), 10 (16-wave 256x256), 45 (ping-pong 256x320).
   // 40/42/47/53/16/12/14/11 are alternative CORRECT tilings kept for tools/gemm_sweep.py (ink_gemm_set_variant).
@@ -639,7 +804,19 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
   // --ablation`, tools/gemm_stamps.py); the shipped library rejects their numbers in ink_gemm_set_variant.
   switch (v) {
     case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s, gm);       // 16 waves x (64x64), 2 x 64 KB stages
-    case 45: return launch_gemm_pp<4, 5>(p, s, generic_epilogue ? -gm : gm);   // ping-pong 256x320, ring of 4 (144 KB)
+    case 45: {                                                          // ping-pong 256x320, ring of 4 (144 KB)
+      if (ext) {       // the ViT-H block forms on the split-f16 stream: one specialised kernel each
+        const bool simple = !p.col_scale && !p.row_map;
+        if (p.ln_stats && p.c_f16 == 1 && simple && !p.residual && !p.res_hi && p.act == INK_ACT_NONE)
+          return launch_gemm_pp<4, 5, 0, true, 1>(p, s, gm);
+        if (p.ln_stats && p.c_f16 == 1 && simple && !p.residual && !p.res_hi && p.act == INK_ACT_GELU)
+          return launch_gemm_pp<4, 5, 0, true, 2>(p, s, gm);
+        if (!p.ln_stats && p.c_f16 == 2 && simple && p.res_hi && p.act == INK_ACT_NONE)
+          return launch_gemm_pp<4, 5, 0, true, 3>(p, s, gm);
+        return launch_gemm<128, 128, 64, 2, 2, 2, 0, true>(p, s);      // any other combination: the general tile
+      }
+      return launch_gemm_pp<4, 5>(p, s, generic_epilogue ? -gm : gm);
+    }
     case 40: return launch_gemm_pp<4>(p, s, gm);                        // ping-pong 256x256, ring of 4 (128 KB)
     case 42: return launch_gemm_pp<3>(p, s, gm);                        // ... ring of 3 (96 KB)
     case 47: return launch_gemm_pp<3, 5>(p, s, gm);                     // 256x320, ring of 3 (DMA 1 granule ahead)
@@ -661,6 +838,6 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     case 51: return launch_gemm_pp<4, 5, 11>(p, s, gm);                 // ... pure DMA stream
     case 52: return launch_gemm_pp<4, 5, 15>(p, s, gm);                 // ... pure DMA stream, all L2 hits
 #endif
-    default: return launch_gemm<128, 128, 64, 2, 2, 2>(p, s);           // variant 0
+    default: return launch_gemm<128, 128, 64, 2, 2, 2, 0, true>(p, s);  // variant 0
   }
 }

@@ -116,7 +116,88 @@ __global__ __launch_bounds__(256) void add_cvt_f16_kernel(const float* __restric
   }
 }
 
+// f32 rows -> the split-f16 residual stream (hi = f16(x), lo = f16(x - hi)) + the per-chunk (sum, sum of squares)
+// partials the folded LayerNorm of the next projection reads (gemm.hip ln_rows_prologue).  One wave per row.
+template <int NV>
+__global__ __launch_bounds__(256) void hilo_split_stats_kernel(const float* __restrict__ x, int64_t ldx, int rows, int C,
+                                                               f16* __restrict__ hi, f16* __restrict__ lo, int64_t ldo,
+                                                               float* __restrict__ stats, int chunk) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = C >> 2, parts = C / chunk;
+  f32x4 r[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int v = lane + 64 * j;
+    r[j] = v < nv ? *(const f32x4*)(x + (int64_t)row * ldx + v * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (v < nv) {
+      f16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h[e] = (f16)r[j][e];
+        l[e] = (f16)(r[j][e] - (float)h[e]);
+      }
+      *(f16x4*)(hi + (int64_t)row * ldo + v * 4) = h;
+      *(f16x4*)(lo + (int64_t)row * ldo + v * 4) = l;
+    }
+  }
+  for (int p = 0; p < parts; ++p) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (c >= p * chunk && c < (p + 1) * chunk) {            // chunk % 4 == 0: a lane's four values share a chunk
+        s1 += (r[j][0] + r[j][1]) + (r[j][2] + r[j][3]);
+        s2 += (r[j][0] * r[j][0] + r[j][1] * r[j][1]) + (r[j][2] * r[j][2] + r[j][3] * r[j][3]);
+      }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) ((float2*)stats)[(int64_t)row * parts + p] = make_float2(s1, s2);
+  }
+}
+
+__global__ __launch_bounds__(256) void hilo_join_kernel(const f16* __restrict__ hi, const f16* __restrict__ lo,
+                                                        float* __restrict__ out, int64_t n4) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f16x4 h = *(const f16x4*)(hi + i * 4), l = *(const f16x4*)(lo + i * 4);
+    *(f32x4*)(out + i * 4) = (f32x4){(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
+                                     (float)h[3] + (float)l[3]};
+  }
+}
+
 }  // namespace
+
+extern "C" int ink_hilo_split_stats(const float* x, int64_t ldx, int32_t rows, int32_t C, void* hi_f16, void* lo_f16,
+                                    int64_t ldo, float* stats, int32_t chunk, void* stream) {
+  INK_CHECK_ARG(x && hi_f16 && lo_f16 && stats && rows > 0 && C > 0 && C % 4 == 0 && C <= 2048);
+  INK_CHECK_ARG(chunk > 0 && chunk % 4 == 0 && C % chunk == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldx >= C && ldo >= C);
+  const dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const int nv = (C / 4 + 63) / 64;
+#define INK_HL(NV) hipLaunchKernelGGL(hilo_split_stats_kernel<NV>, grid, block, 0, s, x, ldx, rows, C, (f16*)hi_f16, \
+                                      (f16*)lo_f16, ldo, stats, chunk)
+  switch (nv) {
+    case 1: INK_HL(1); break;
+    case 2: INK_HL(2); break;
+    case 3: INK_HL(3); break;
+    case 4: INK_HL(4); break;
+    case 5: INK_HL(5); break;
+    default: INK_HL(8); break;
+  }
+#undef INK_HL
+  return ink_launch_status();
+}
+
+extern "C" int ink_hilo_join(const void* hi_f16, const void* lo_f16, int64_t n, float* out, void* stream) {
+  INK_CHECK_ARG(hi_f16 && lo_f16 && out && n > 0 && n % 4 == 0);
+  const int64_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(hilo_join_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)hi_f16,
+                     (const f16*)lo_f16, out, n4);
+  return ink_launch_status();
+}
 
 extern "C" int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamma,
                                   const float* beta, float eps, const int32_t* gather,

@@ -75,21 +75,30 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          act: Optional[str] = None, residual: Optional[torch.Tensor] = None,
          col_scale: Optional[torch.Tensor] = None, row_map: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, out_dtype: torch.dtype = F32,
-         out_rows: Optional[int] = None) -> torch.Tensor:
+         out_rows: Optional[int] = None, residual_hilo=None, out_hilo=None,
+         stats_out: Optional[torch.Tensor] = None, ln=None) -> torch.Tensor:
     """out[row_map[m]] = residual[row_map[m]] + col_scale * act(a[m] @ w.T + bias).
 
     a: f16 [M, K] (row stride arbitrary, multiple of 8), w: f16 [N, K].
-    """
+    Split-f16 stream forms (SAM ViT-H blocks): residual_hilo = (hi, lo) f16 planes instead of `residual`;
+    out_hilo = (hi, lo) f16 planes instead of `out` (returns hi); stats_out f32 [rows, N / chunk, 2] receives the
+    per-chunk (sum, sum of squares) of every output row (chunk = gemm_stats_chunk(M, N, K));
+    ln = (stats [M, parts, 2], dim, eps, colsum [N]): LayerNorm over the `dim` source columns of a's rows folded in
+    (w carries gamma, bias carries beta w^T + b)."""
     assert a.dtype == F16 and w.dtype == F16
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K
+    p = InkGemm()
+    if out_hilo is not None:
+        out, out_lo = out_hilo
+        assert out.dtype == F16 and out_lo.dtype == F16 and out_lo.shape == out.shape and out_lo.stride() == out.stride()
+        p.C_lo = out_lo.data_ptr()
     if out is None:
         rows = out_rows if out_rows is not None else M
         out = torch.empty((rows, N), device=a.device, dtype=out_dtype)
     assert out.dim() == 2 and out.stride(1) == 1 and out.shape[1] == N
-    p = InkGemm()
     p.A, p.W, p.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     p.bias, p.col_scale = _p(bias), _p(col_scale)
     p.residual, p.row_map = _p(residual), _p(row_map)
@@ -102,11 +111,26 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         p.ldr = residual.stride(0)
     if row_map is not None:
         assert row_map.dtype == torch.int32 and row_map.numel() == M
+    if residual_hilo is not None:
+        rh, rl = residual_hilo
+        assert residual is None and rh.dtype == F16 and rl.dtype == F16 and rh.stride(1) == 1 and rh.shape[1] == N
+        assert rl.shape == rh.shape and rl.stride() == rh.stride()
+        p.res_hi, p.res_lo, p.ldr = rh.data_ptr(), rl.data_ptr(), rh.stride(0)
     p.M, p.N, p.K = M, N, K
     p.lda, p.ldw, p.ldc = a.stride(0), w.stride(0), out.stride(0)
     p.act = ACT[act]
-    p.c_f16 = 1 if out.dtype == F16 else 0
+    p.c_f16 = 2 if out_hilo is not None else (1 if out.dtype == F16 else 0)
     assert out.dtype in (F16, F32)
+    if stats_out is not None:
+        chunk = gemm_stats_chunk(M, N, K)
+        assert out_hilo is not None and N % chunk == 0 and stats_out.dtype == F32 and stats_out.is_contiguous()
+        assert tuple(stats_out.shape) == (out.shape[0], N // chunk, 2)
+        p.stats_out, p.stats_parts = stats_out.data_ptr(), N // chunk
+    if ln is not None:
+        st, dim, eps, colsum = ln
+        assert st.dtype == F32 and st.is_contiguous() and st.dim() == 3 and st.shape[0] == M and st.shape[2] == 2
+        assert colsum.dtype == F32 and colsum.numel() == N and row_map is None
+        p.ln_stats, p.ln_parts, p.ln_dim, p.ln_eps, p.ln_colsum = st.data_ptr(), st.shape[1], int(dim), float(eps), colsum.data_ptr()
     if _GEMM_TRACE is None:
         check(_lib.lib().ink_gemm_f16(C.byref(p), _stream()), "ink_gemm_f16")
     else:
@@ -116,6 +140,31 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         e1.record()
         _GEMM_TRACE.append((2.0 * M * N * K, e0, e1, (M, N, K, act or '-', 'res' if residual is not None else '-',
                                                       'map' if row_map is not None else '-', 'f16' if p.c_f16 else 'f32')))
+    return out
+
+
+def gemm_stats_chunk(M: int, N: int, K: int) -> int:
+    """Columns per row-statistics chunk of the kernel ink_gemm_f16 picks for this (split-output) shape."""
+    return int(_lib.lib().ink_gemm_query_stats_chunk(M, N, K))
+
+
+def hilo_split_stats(x: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor, stats: torch.Tensor, chunk: int) -> None:
+    """f32 rows -> the split-f16 stream (hi = f16(x), lo = f16(x - hi)) + per-chunk (sum, sum of squares) [rows, C/chunk, 2]."""
+    assert x.dtype == F32 and x.dim() == 2 and x.stride(1) == 1 and hi.dtype == F16 and lo.dtype == F16
+    rows, Cdim = x.shape
+    assert hi.shape == x.shape and lo.shape == x.shape and hi.stride() == lo.stride() and hi.stride(1) == 1
+    assert stats.dtype == F32 and stats.is_contiguous() and tuple(stats.shape) == (rows, Cdim // chunk, 2)
+    check(_lib.lib().ink_hilo_split_stats(x.data_ptr(), x.stride(0), rows, Cdim, hi.data_ptr(), lo.data_ptr(), hi.stride(0),
+                                          stats.data_ptr(), chunk, _stream()), "ink_hilo_split_stats")
+
+
+def hilo_join(hi: torch.Tensor, lo: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f32 (hi + lo) of two contiguous f16 planes."""
+    assert hi.dtype == F16 and lo.dtype == F16 and hi.is_contiguous() and lo.is_contiguous() and hi.shape == lo.shape
+    if out is None:
+        out = torch.empty(hi.shape, device=hi.device, dtype=F32)
+    assert out.dtype == F32 and out.is_contiguous() and out.shape == hi.shape
+    check(_lib.lib().ink_hilo_join(hi.data_ptr(), lo.data_ptr(), hi.numel(), out.data_ptr(), _stream()), "ink_hilo_join")
     return out
 
 

@@ -292,11 +292,15 @@ def refine_masks(cleaned_masks: torch.Tensor, boxes_px: Sequence[Sequence[int]],
     ranks_dev = _i32(ranks, dev) if n else None
     check(L.ink_refine_composite(planes.data_ptr() if n else None, ranks_dev.data_ptr() if n else None, len(ranks), H, W,
                                  label.data_ptr(), hist.data_ptr(), st), "ink_refine_composite")
-    hist_h = hist.cpu().numpy()
+    hist_h = hist.cpu().numpy().astype(np.int64)
+    hist_h[0] = H * W - int(hist_h[1:].sum())
+    # `np.unique(composite)[1:]` (refiner.py:49): the reference drops the SMALLEST value present, which is the
+    # background 0 - unless the masks cover every pixel, in which case the first mask label goes instead (kept as is)
+    present = [l for l in range(len(ranks) + 1) if hist_h[l] > 0][1:]
     lut = np.zeros(256, np.uint8)
     info, n_dis = [], 0
     for r, m in enumerate(ranks):
-        if m < 0 or hist_h[r + 1] == 0:
+        if m < 0 or (r + 1) not in present:
             continue                          # no pixel carries this label
         if hist_h[r + 1] < 0.05 * per_h[m, 0] and any(ranks[q] >= 0 and pair_h[m, ranks[q], 0] > 0 for q in range(r)):
             continue                          # nearly hidden and overlapping an earlier mask: merged away

@@ -87,12 +87,17 @@ class SamEngine:
     """Weights packed for the HIP kernels + preallocated activations for up to `max_batch` images."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[SamConfig] = None,
-                 device: str | torch.device = "cuda", max_batch: int = 1, precise_tail: bool = True):
+                 device: str | torch.device = "cuda", max_batch: int = 1, precise_tail: bool = True,
+                 ln_fold: bool = True):
         """precise_tail=True (the product setting): neck + decoder on split-f16 operands.  False keeps the plain
-        f16 tail of round 1 (faster by a few %, mask IoU 0.998 instead of >= 0.999; kept for A/B measurements)."""
+        f16 tail of round 1 (faster by a few %, mask IoU 0.998 instead of >= 0.999; kept for A/B measurements).
+        ln_fold=True (the product setting): the residual stream of the 32 blocks lives as two f16 planes (hi + lo), the
+        hi plane is the operand of qkv / lin1 and both LayerNorms are folded into those projections - no LayerNorm
+        kernel and no conversion pass ever reads the stream.  False: f32 stream + layernorm_rows (rounds 1-2; A/B)."""
         cfg = cfg or SamConfig()
         self.cfg, self.dev = cfg, torch.device(device)
         self.precise_tail = bool(precise_tail)
+        self.ln_fold = bool(ln_fold)
         assert self.dev.type == "cuda", "the InkLayer segmentor runs on MI355X only"
         D, g = cfg.embed_dim, cfg.grid
         assert D // cfg.num_heads == 80 and g == 64 and cfg.window_size == 14, \
@@ -127,6 +132,17 @@ class SamEngine:
                 w[f"b{i}.{n}"] = f(p + n)
             for n in ("attn.qkv.weight", "attn.proj.weight", "mlp.lin1.weight", "mlp.lin2.weight"):
                 w[f"b{i}.{n}"] = h(p + n)
+            if self.ln_fold:
+                # LayerNorm folded into the projection that consumes it: W' = gamma o W in f16, its row
+                # sums (of the ROUNDED weights: what the MFMA really multiplies the mean with) and beta W^T + b
+                for lin, nrm in (("attn.qkv", "norm1"), ("mlp.lin1", "norm2")):
+                    W32 = sd[p + lin + ".weight"].detach().to(dev, torch.float32)
+                    g32, b32 = w[f"b{i}.{nrm}.weight"], w[f"b{i}.{nrm}.bias"]
+                    wl = (W32 * g32[None, :]).to(F16).contiguous()
+                    w[f"b{i}.{lin}.w_ln"] = wl
+                    w[f"b{i}.{lin}.colsum"] = wl.double().sum(1).float().contiguous()
+                    w[f"b{i}.{lin}.bias_ln"] = (W32.double() @ b32.double() + w[f"b{i}.{lin}.bias"].double()).float().contiguous()
+                    del w[f"b{i}.{lin}.weight"]               # the unfolded f16 copy is not used on this path
             if i not in cfg.global_attn_indexes:
                 # window padding (image_encoder.py:256-259 pads AFTER norm1 with zeros): the k / v rows of a
                 # padded token are qkv(0) = the bias, rounded to f16 exactly like a projected row would be
@@ -272,6 +288,11 @@ class SamEngine:
         self.buf_patches = e(B * T, 3 * P * P * (3 if self.precise_tail else 1))
         self.x = e(B * T, D, dt=F32)
         self.y = e(B * T, D)
+        if self.ln_fold:
+            self.x_hi, self.x_lo = e(B * T, D), e(B * T, D)
+            # row statistics of the stream, per column chunk of the projection kernel that writes them (the chunk
+            # width depends on the tile variant the row count selects: sized for the finest one, viewed per call)
+            self.x_stats = e(B * T * (D // 64) * 2, dt=F32)
         self.qkv = e(B * T, 3 * D)
         self.att = e(B * T, D)
         self.hid = e(B * T, int(D * cfg.mlp_ratio))
@@ -341,28 +362,43 @@ class SamEngine:
         H, Mw = cfg.num_heads, self.Mw
         x = self.x[:B * T]
         nblk = cfg.depth if upto is None else upto
+        fold = self.ln_fold
+        if fold:
+            # the stream as two f16 planes + its row statistics (written by every projection that updates it)
+            xh, xl = self.x_hi[:B * T], self.x_lo[:B * T]
+            chunk = ops.gemm_stats_chunk(B * T, D, D)
+            st = self.x_stats[:B * T * (D // chunk) * 2].view(B * T, D // chunk, 2)
+            ops.hilo_split_stats(x, xh, xl, st, chunk)
+            hilo = (xh, xl)
+
+        def qkv_of(k):
+            if fold:
+                return ops.gemm(xh, w[k + "attn.qkv.w_ln"], w[k + "attn.qkv.bias_ln"], out=self.qkv[:B * T],
+                                ln=(st, D, 1e-6, w[k + "attn.qkv.colsum"]))
+            y = ops.layernorm_rows(x, w[k + "norm1.weight"], w[k + "norm1.bias"], 1e-6, out=self.y[:B * T])
+            return ops.gemm(y, w[k + "attn.qkv.weight"], w[k + "attn.qkv.bias"], out=self.qkv[:B * T])
+
+        def add_proj(k, o):
+            if fold:
+                ops.gemm(o, w[k + "attn.proj.weight"], w[k + "attn.proj.bias"], residual_hilo=hilo, out_hilo=hilo, stats_out=st)
+            else:
+                ops.gemm(o, w[k + "attn.proj.weight"], w[k + "attn.proj.bias"], residual=x, out=x)
+
         for i in range(nblk):
             k = f"b{i}."
+            qkv = qkv_of(k)
+            q, kk, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
             if i in cfg.global_attn_indexes:
-                y = ops.layernorm_rows(x, w[k + "norm1.weight"], w[k + "norm1.bias"], 1e-6,
-                                       out=self.y[:B * T])
-                qkv = ops.gemm(y, w[k + "attn.qkv.weight"], w[k + "attn.qkv.bias"], out=self.qkv[:B * T])
-                q, kk, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
                 rh, rw = ops.relpos_bias(q, w[k + "attn.rel_pos_h"], w[k + "attn.rel_pos_w"], S=cfg.grid,
                                          n_batch=B, n_heads=H, head_dim=80, scale=self.scale,
                                          out=(self.rel_h, self.rel_w))
                 o = ops.flash_attn(q, kk, v, n_batch=B, n_heads=H, head_dim=80, scale=self.scale,
                                    rel_h=rh, rel_w=rw, grid_w=cfg.grid, out=self.att[:B * T])
-                ops.gemm(o, w[k + "attn.proj.weight"], w[k + "attn.proj.bias"], residual=x, out=x)
             else:
                 # windowed block: everything stays in token order; window_partition / window_unpartition
                 # (image_encoder.py:243-289) is the token-row map the attention gathers and scatters through,
                 # so the 19.6 % padding rows (70x70 vs 64x64) are never normalised, projected or written
                 wm = self.win_map[:B * Mw]
-                y = ops.layernorm_rows(x, w[k + "norm1.weight"], w[k + "norm1.bias"], 1e-6,
-                                       out=self.y[:B * T])
-                qkv = ops.gemm(y, w[k + "attn.qkv.weight"], w[k + "attn.qkv.bias"], out=self.qkv[:B * T])
-                q, kk, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
                 nb = B * self.nwin * self.nwin
                 aug = ops.relpos_bias(q, w[k + "attn.rel_pos_h"], w[k + "attn.rel_pos_w"],
                                       S=cfg.window_size, n_batch=nb, n_heads=H, head_dim=80,
@@ -371,11 +407,17 @@ class SamEngine:
                                    n_q=cfg.window_size ** 2, n_k=cfg.window_size ** 2,
                                    rel_aug=aug, grid_w=cfg.window_size, tok_rows=wm,
                                    pad_k=w[k + "pad_k"], pad_v=w[k + "pad_v"], out=self.att[:B * T])
-                ops.gemm(o, w[k + "attn.proj.weight"], w[k + "attn.proj.bias"], residual=x, out=x)
-            y = ops.layernorm_rows(x, w[k + "norm2.weight"], w[k + "norm2.bias"], 1e-6, out=self.y[:B * T])
-            hd = ops.gemm(y, w[k + "mlp.lin1.weight"], w[k + "mlp.lin1.bias"], act="gelu",
-                          out=self.hid[:B * T])
-            ops.gemm(hd, w[k + "mlp.lin2.weight"], w[k + "mlp.lin2.bias"], residual=x, out=x)
+            add_proj(k, o)
+            if fold:
+                hd = ops.gemm(xh, w[k + "mlp.lin1.w_ln"], w[k + "mlp.lin1.bias_ln"], act="gelu", out=self.hid[:B * T],
+                              ln=(st, D, 1e-6, w[k + "mlp.lin1.colsum"]))
+                ops.gemm(hd, w[k + "mlp.lin2.weight"], w[k + "mlp.lin2.bias"], residual_hilo=hilo, out_hilo=hilo, stats_out=st)
+            else:
+                y = ops.layernorm_rows(x, w[k + "norm2.weight"], w[k + "norm2.bias"], 1e-6, out=self.y[:B * T])
+                hd = ops.gemm(y, w[k + "mlp.lin1.weight"], w[k + "mlp.lin1.bias"], act="gelu", out=self.hid[:B * T])
+                ops.gemm(hd, w[k + "mlp.lin2.weight"], w[k + "mlp.lin2.bias"], residual=x, out=x)
+        if fold:
+            ops.hilo_join(xh, xl, out=x)                 # f32 view of the stream for the neck / the stage taps
         if upto is not None:
             return x.view(B, T, D)
         # neck (image_encoder.py:88-104): 1x1 conv -> LN2d -> 3x3 conv -> LN2d, all on NHWC tokens

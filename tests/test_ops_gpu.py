@@ -358,3 +358,63 @@ def test_attn_fewq_forms(dev, n_heads, n_k, shared):
     vf = v.double().view(nkv, n_k, n_heads, hd).transpose(1, 2)[owner]
     ref = (torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(hd), -1) @ vf).transpose(1, 2).reshape(n * nq, n_heads * hd)
     assert (out.double() - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-5
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("M", [1000, 24576 + 100])
+def test_gemm_split_stream_and_layernorm_fold(dev, M):
+    """ABI-4 forms of ink_gemm_f16 (the SAM ViT-H block on the split-f16 residual stream), on the 128x128 tile (M = 1000)
+    and on the specialised ping-pong kernels (M = 24676: N % 320 == 0 and >= 384 tiles, with a ragged last tile):
+      * split residual in, split C + per-chunk row statistics out (proj / lin2);
+      * LayerNorm folded into the projection (qkv; lin1 + GELU), fed by those statistics."""
+    from inklayer_amd import ops
+    g = torch.Generator().manual_seed(5)
+    D = 1280
+    x = (torch.randn(M, D, generator=g) * 1.5 + 0.7 * torch.randn(M, 1, generator=g)).to(dev)
+    chunk = ops.gemm_stats_chunk(M, D, D)
+    assert chunk == (80 if M > 20000 else 64)
+    hi, lo = torch.empty(M, D, device=dev, dtype=torch.float16), torch.empty(M, D, device=dev, dtype=torch.float16)
+    st = torch.empty(M, D // chunk, 2, device=dev)
+    ops.hilo_split_stats(x, hi, lo, st, chunk)
+    xd = x.double()
+    rec = hi.double() + lo.double()
+    assert ((rec - xd).abs() / xd.abs().clamp(min=1e-3)).max().item() < 2e-6          # ~22 significant bits
+    assert torch.equal(ops.hilo_join(hi, lo), (hi.float() + lo.float()))
+    parts = xd.view(M, D // chunk, chunk)
+    assert (st[..., 0].double() - parts.sum(-1)).abs().max().item() < 1e-3
+    assert ((st[..., 1].double() - (parts ** 2).sum(-1)).abs() / (parts ** 2).sum(-1)).max().item() < 1e-5
+    # ---- folded LayerNorm: qkv form (f16 out) and lin1 form (GELU)
+    gam = (1.0 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    bet = (0.1 * torch.randn(D, generator=g)).to(dev)
+    for N, act in ((3840, None), (2560, "gelu")):
+        W = (torch.randn(N, D, generator=g) / D ** 0.5).to(dev)
+        b = (0.1 * torch.randn(N, generator=g)).to(dev)
+        wl = (W * gam[None]).half().contiguous()
+        colsum = wl.double().sum(1).float().contiguous()
+        bias_ln = (W.double() @ bet.double() + b.double()).float().contiguous()
+        out = ops.gemm(hi, wl, bias_ln, act=act, out_dtype=torch.float16, ln=(st, D, 1e-6, colsum))
+        mean = xd.mean(1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-6)
+        want = rstd * ((hi.double() - mean) @ wl.double().t()) + bias_ln.double()       # the fold's own arithmetic, in f64
+        if act == "gelu":
+            want = torch.nn.functional.gelu(want)
+        err = (out.double() - want).abs().max().item() / want.abs().max().item()
+        # ... and against LayerNorm -> Linear on the unrounded f32 operands (what the reference computes)
+        ref = torch.nn.functional.layer_norm(xd, (D,), gam.double(), bet.double(), 1e-6) @ W.double().t() + b.double()
+        if act == "gelu":
+            ref = torch.nn.functional.gelu(ref)
+        l2 = ((out.double() - ref).norm() / ref.norm()).item()
+        print(f"M={M} N={N} act={act}: vs fold-in-f64 max-rel {err:.2e} (f16 output rounding), vs fp32 LN+Linear l2-rel {l2:.2e}")
+        assert err < 1.5e-3 and l2 < 1.5e-3
+    # ---- projection on the split stream: residual in, C + statistics out, in place
+    Wp = (torch.randn(D, D, generator=g) / D ** 0.5).to(dev).half()
+    bp = (0.1 * torch.randn(D, generator=g)).to(dev)
+    a = torch.randn(M, D, generator=g).to(dev).half()
+    want = rec + a.double() @ Wp.double().t() + bp.double()
+    st2 = torch.zeros_like(st)
+    ops.gemm(a, Wp, bp, residual_hilo=(hi, lo), out_hilo=(hi, lo), stats_out=st2)
+    got = hi.double() + lo.double()
+    assert ((got - want).abs().max() / want.abs().max()).item() < 3e-6
+    wp = want.view(M, D // chunk, chunk)
+    assert (st2[..., 0].double() - wp.sum(-1)).abs().max().item() < 2e-3
+    assert ((st2[..., 1].double() - (wp ** 2).sum(-1)).abs() / (wp ** 2).sum(-1)).max().item() < 2e-5

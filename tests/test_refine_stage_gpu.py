@@ -185,6 +185,13 @@ def test_whole_stage_on_random_masks_odd_sizes_and_edge_cases(dev):
     one = np.zeros((120, 200), np.uint8)
     one[30:90, 40:160] = 255
     _assert_stage_equals_oracle(dev, [one], [[40, 30, 160, 90]], rgb, _synthetic_depth(120, 200, 2), "one mask")
+    # masks that cover EVERY pixel: np.unique(composite)[1:] then drops the first mask label instead of the background
+    # (a reference quirk that random-weight masks after the k x k closing do hit)
+    full = [np.full((120, 200), 255, np.uint8), one.copy()]
+    full[0][:, :100] = 0
+    full[1][:, :100] = 255
+    res = _assert_stage_equals_oracle(dev, full, [[100, 0, 199, 119], [0, 0, 160, 119]], rgb, _synthetic_depth(120, 200, 4), "full cover")
+    assert res.n_disjoint == 1
 
 
 def test_plugin_surfaces_of_the_stage(dev, tmp_path):
