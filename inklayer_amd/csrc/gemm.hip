@@ -121,23 +121,30 @@ __device__ __forceinline__ void ln_rows_prologue(const InkGemm& p, float2* strip
     const int n = nw + c;
     cols[c] = n < p.N ? make_float2(p.ln_colsum[n], p.bias ? p.bias[n] : 0.f) : make_float2(0.f, 0.f);
   }
-  for (int r = lane; r < TM * 16; r += 64) {
-    const int m = mw + r;
-    float2 o = make_float2(0.f, 0.f);
-    if (m < p.M) {
-      const float2* sp = (const float2*)p.ln_stats + (size_t)m * p.ln_parts;
-      double s1 = 0.0, s2 = 0.0;
-      for (int k = 0; k < p.ln_parts; ++k) {
-        const float2 v = sp[k];
-        s1 += (double)v.x;
-        s2 += (double)v.y;
-      }
-      const double mean = s1 / (double)p.ln_dim;
-      const double var = fmax(s2 / (double)p.ln_dim - mean * mean, 0.0);
-      const float rstd = (float)(1.0 / sqrt(var + (double)p.ln_eps));
-      o = make_float2(rstd, rstd * (float)mean);
+  // a row's partials are ln_parts (<= 20, even) contiguous float2: ten 16-B loads, all in flight before the first use
+  // (a run-time-bounded scalar loop would serialise ln_parts dependent round trips per row)
+  constexpr int RPL = (TM * 16 + 63) / 64;                  // rows per lane
+  f32x4 v[RPL][10];
+#pragma unroll
+  for (int q = 0; q < RPL; ++q) {
+    const int r = lane + 64 * q, m = mw + r;
+    const f32x4* sp = (const f32x4*)((const float2*)p.ln_stats + (size_t)min(m, p.M - 1) * p.ln_parts);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v[q][k] = 2 * k < p.ln_parts ? sp[k] : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int q = 0; q < RPL; ++q) {
+    const int r = lane + 64 * q;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      s1 += (double)v[q][k][0] + (double)v[q][k][2];
+      s2 += (double)v[q][k][1] + (double)v[q][k][3];
     }
-    strip[r] = o;
+    const double mean = s1 / (double)p.ln_dim;
+    const double var = fmax(s2 / (double)p.ln_dim - mean * mean, 0.0);
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.ln_eps));
+    if (r < TM * 16) strip[r] = mw + r < p.M ? make_float2(rstd, rstd * (float)mean) : make_float2(0.f, 0.f);
   }
 }
 
@@ -778,7 +785,8 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
   INK_CHECK_ARG(p.c_f16 >= 0 && p.c_f16 <= 2 && (p.c_f16 != 2 || (p.C_lo && ((uintptr_t)p.C_lo & 15) == 0)));
   INK_CHECK_ARG(!p.res_hi || (p.res_lo && !p.residual && p.ldr % 4 == 0 && p.ldr >= p.N && p.act == INK_ACT_NONE &&
                               !p.col_scale));
-  INK_CHECK_ARG(!p.ln_stats || (p.ln_colsum && p.ln_parts > 0 && p.ln_dim > 0 && !p.row_map));
+  INK_CHECK_ARG(!p.ln_stats || (p.ln_colsum && p.ln_parts > 0 && p.ln_parts <= 20 && p.ln_parts % 2 == 0 &&
+                                p.ln_dim > 0 && !p.row_map && ((uintptr_t)p.ln_stats & 15) == 0));
   hipStream_t s = (hipStream_t)stream;
   int v = g_variant;           // -1 (default): shape heuristic.  No environment variable reaches this function.
   int gm = 1;

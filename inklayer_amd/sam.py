@@ -88,12 +88,14 @@ class SamEngine:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[SamConfig] = None,
                  device: str | torch.device = "cuda", max_batch: int = 1, precise_tail: bool = True,
-                 ln_fold: bool = True):
+                 ln_fold: bool = True, bias_correction: bool = True):
         """precise_tail=True (the product setting): neck + decoder on split-f16 operands.  False keeps the plain
         f16 tail of round 1 (faster by a few %, mask IoU 0.998 instead of >= 0.999; kept for A/B measurements).
         ln_fold=True (the product setting): the residual stream of the 32 blocks lives as two f16 planes (hi + lo), the
         hi plane is the operand of qkv / lin1 and both LayerNorms are folded into those projections - no LayerNorm
-        kernel and no conversion pass ever reads the stream.  False: f32 stream + layernorm_rows (rounds 1-2; A/B)."""
+        kernel and no conversion pass ever reads the stream.  False: f32 stream + layernorm_rows (rounds 1-2; A/B).
+        bias_correction=True (the product setting): the biases of the 4 x 32 block projections absorb the EXPECTED error
+        of rounding their weights to f16 (see _calibrate_bias_correction)."""
         cfg = cfg or SamConfig()
         self.cfg, self.dev = cfg, torch.device(device)
         self.precise_tail = bool(precise_tail)
@@ -210,6 +212,39 @@ class SamEngine:
         if self.precise_tail:
             self._pack_split(sd)
         self._alloc(max_batch)
+        if bias_correction:
+            self._calibrate_bias_correction(sd)
+
+    # ------------------------------------------------------------------ load-time bias correction
+    @torch.no_grad()
+    def _calibrate_bias_correction(self, sd) -> None:
+        """More than half of the energy of the ViT-H residual stream - and of the attention / GELU outputs - is a
+        per-channel constant (the same for every token, nearly the same for every sketch).  Rounding a weight matrix to
+        f16 therefore produces, besides noise, a SYSTEMATIC output error  sum_k (W - f16(W))[n, k] * mean_k  that is the
+        same for every token: a bias error.  It is measured once, at load time, on a calibration page (one encoder
+        forward of this engine on a blank sketch page; torch reductions, never on the hot path) and folded into the bias:
+        b_n += sum_k (W_eff - f16(W_eff))[n, k] * mean_k,  W_eff = the weights as the kernel sees them (gamma o W for the
+        LayerNorm-folded projections, whose operand mean is that of the normalised stream).  Zero run-time cost; measured
+        with tests/precision_study.py it halves the logit error of the 32 blocks (the known "bias correction" of
+        post-training quantisation, applied to f16)."""
+        cfg, w, D = self.cfg, self.w, self.cfg.embed_dim
+        page = torch.full((cfg.img_size, cfg.img_size, 3), 255, dtype=torch.uint8, device=self.dev)
+        means: Dict[str, torch.Tensor] = {}
+        self._calib = means
+        try:
+            self.encode([page])
+        finally:
+            self._calib = None
+        for i in range(cfg.depth):
+            p = f"image_encoder.blocks.{i}."
+            for lin, nrm in (("attn.qkv", "norm1"), ("mlp.lin1", "norm2"), ("attn.proj", None), ("mlp.lin2", None)):
+                W32 = sd[p + lin + ".weight"].detach().to(self.dev, torch.float32)
+                if nrm is not None and self.ln_fold:
+                    W32 = W32 * w[f"b{i}.{nrm}.weight"][None, :]
+                    w16, bias = w[f"b{i}.{lin}.w_ln"], w[f"b{i}.{lin}.bias_ln"]
+                else:
+                    w16, bias = w[f"b{i}.{lin}.weight"], w[f"b{i}.{lin}.bias"]
+                bias += ((W32 - w16.float()).double() @ means[f"b{i}.{lin}"].double()).float()
 
     def _pack_split(self, sd) -> None:
         """Split-f16 weight copies [N, 3K] (ops.split_weight) of the neck / decoder matrices, keyed '<name>.ws'."""
@@ -371,11 +406,23 @@ class SamEngine:
             ops.hilo_split_stats(x, xh, xl, st, chunk)
             hilo = (xh, xl)
 
+        calib = getattr(self, "_calib", None)
+
+        def note(key, lin, nrm):
+            """calibration pass only: per-channel mean (over the tokens) of the operand of projection `lin` as the
+            kernel's arithmetic sees it - the normalised stream for a folded LayerNorm, else the f16 operand"""
+            if calib is not None and fold:
+                x32 = ops.hilo_join(xh, xl)
+                calib[key + lin] = torch.nn.functional.layer_norm(x32, (D,), None, None, 1e-6).mean(0)
+
         def qkv_of(k):
+            note(k, "attn.qkv", "norm1")
             if fold:
                 return ops.gemm(xh, w[k + "attn.qkv.w_ln"], w[k + "attn.qkv.bias_ln"], out=self.qkv[:B * T],
                                 ln=(st, D, 1e-6, w[k + "attn.qkv.colsum"]))
             y = ops.layernorm_rows(x, w[k + "norm1.weight"], w[k + "norm1.bias"], 1e-6, out=self.y[:B * T])
+            if calib is not None:
+                calib[k + "attn.qkv"] = y.float().mean(0)
             return ops.gemm(y, w[k + "attn.qkv.weight"], w[k + "attn.qkv.bias"], out=self.qkv[:B * T])
 
         def add_proj(k, o):
@@ -407,14 +454,21 @@ class SamEngine:
                                    n_q=cfg.window_size ** 2, n_k=cfg.window_size ** 2,
                                    rel_aug=aug, grid_w=cfg.window_size, tok_rows=wm,
                                    pad_k=w[k + "pad_k"], pad_v=w[k + "pad_v"], out=self.att[:B * T])
+            if calib is not None:
+                calib[k + "attn.proj"] = o.float().mean(0)
             add_proj(k, o)
             if fold:
+                note(k, "mlp.lin1", "norm2")
                 hd = ops.gemm(xh, w[k + "mlp.lin1.w_ln"], w[k + "mlp.lin1.bias_ln"], act="gelu", out=self.hid[:B * T],
                               ln=(st, D, 1e-6, w[k + "mlp.lin1.colsum"]))
+                if calib is not None:
+                    calib[k + "mlp.lin2"] = hd.float().mean(0)
                 ops.gemm(hd, w[k + "mlp.lin2.weight"], w[k + "mlp.lin2.bias"], residual_hilo=hilo, out_hilo=hilo, stats_out=st)
             else:
                 y = ops.layernorm_rows(x, w[k + "norm2.weight"], w[k + "norm2.bias"], 1e-6, out=self.y[:B * T])
                 hd = ops.gemm(y, w[k + "mlp.lin1.weight"], w[k + "mlp.lin1.bias"], act="gelu", out=self.hid[:B * T])
+                if calib is not None:
+                    calib[k + "mlp.lin1"], calib[k + "mlp.lin2"] = y.float().mean(0), hd.float().mean(0)
                 ops.gemm(hd, w[k + "mlp.lin2.weight"], w[k + "mlp.lin2.bias"], residual=x, out=x)
         if fold:
             ops.hilo_join(xh, xl, out=x)                 # f32 view of the stream for the neck / the stage taps

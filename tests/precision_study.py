@@ -45,6 +45,14 @@ class QuantF:
 
     def _wrap(self, fn, x, w, *a, **kw):
         fl = self._flags(w)
+        if ("c" in fl or "z" in fl) and fn is RealF.linear:
+            # channel-centred operands (round-3 study): x = cm + s with cm the per-channel mean over the tokens; only s is
+            # rounded ("c"), and the mean's product with the weights is exact ("z": cm W^T in fp32 instead of cm f16(W)^T)
+            cm = x.reshape(-1, x.shape[-1]).mean(0)
+            s_ = r16(x - cm) if ("a" in fl and "c" in fl) else (r16(x) - cm if "a" in fl else x - cm)
+            w16 = r16(w) if "w" in fl else w
+            y = fn(s_, w16, *a, **kw) + RealF.linear(cm, w if "z" in fl else w16)
+            return r16(y) if "o" in fl else y
         if "a" in fl:
             x = r16(x)
         if "w" in fl:
@@ -65,6 +73,10 @@ class QuantF:
 POLICIES = {
     "all-f16 (round-1 design)": [(r"qkv|lin1", "awo"), (r".", "aw")],
     "encoder blocks only": [(r"blocks.*(qkv|lin1)", "awo"), (r"blocks|patch_embed", "aw")],
+    "blocks (no patch embed)": [(r"blocks.*(qkv|lin1)", "awo"), (r"blocks", "aw")],
+    "blocks, centred activations": [(r"blocks.*(qkv|lin1)", "awoc"), (r"blocks", "awc")],
+    "blocks, centred + exact mean product": [(r"blocks.*(qkv|lin1)", "awocz"), (r"blocks", "awcz")],
+    "blocks, exact mean product only": [(r"blocks.*(qkv|lin1)", "awoz"), (r"blocks", "awz")],
     "encoder: weights only": [(r"blocks|patch_embed", "w")],
     "encoder: activations only": [(r"blocks.*(qkv|lin1)", "ao"), (r"blocks|patch_embed", "a")],
     "encoder: qkv": [(r"blocks.*qkv", "awo")],
