@@ -535,8 +535,10 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
     }
   };
   stamp_rt(0);
-  const float* dbg_out = p.residual;
-  if (ABL & 8) p.residual = nullptr;
+  const float* dbg_out = EPI ? p.col_scale : p.residual;        // (stamp builds: the timeline leaves through a spare pointer)
+  if (ABL & 8) {
+    if (EPI) p.col_scale = nullptr; else p.residual = nullptr;
+  }
 
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
@@ -763,7 +765,8 @@ extern "C" int ink_gemm_set_variant(int32_t v) {
   bool ok = base == -1 || base == 0 || base == 10 || base == 11 || base == 12 || base == 14 || base == 16 ||
             base == 32 || base == 40 || base == 42 || base == 45 || base == 47 || base == 53;
 #ifdef INK_ABLATION
-  ok = ok || (base >= 21 && base <= 23) || base == 43 || base == 44 || base == 46 || (base >= 48 && base <= 52);
+  ok = ok || (base >= 21 && base <= 23) || base == 43 || base == 44 || base == 46 || (base >= 48 && base <= 52) ||
+       (base >= 61 && base <= 63);
 #endif
   INK_CHECK_ARG(ok);
   g_variant = v;
@@ -783,8 +786,10 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
   INK_CHECK_ARG(((uintptr_t)p.C & 15) == 0);
   INK_CHECK_ARG(p.act >= 0 && p.act <= 2);
   INK_CHECK_ARG(p.c_f16 >= 0 && p.c_f16 <= 2 && (p.c_f16 != 2 || (p.C_lo && ((uintptr_t)p.C_lo & 15) == 0)));
-  INK_CHECK_ARG(!p.res_hi || (p.res_lo && !p.residual && p.ldr % 4 == 0 && p.ldr >= p.N && p.act == INK_ACT_NONE &&
-                              !p.col_scale));
+#ifndef INK_ABLATION      // (the stamp builds pass their debug buffer through col_scale)
+  INK_CHECK_ARG(!p.res_hi || !p.col_scale);
+#endif
+  INK_CHECK_ARG(!p.res_hi || (p.res_lo && !p.residual && p.ldr % 4 == 0 && p.ldr >= p.N && p.act == INK_ACT_NONE));
   INK_CHECK_ARG(!p.ln_stats || (p.ln_colsum && p.ln_parts > 0 && p.ln_parts <= 20 && p.ln_parts % 2 == 0 &&
                                 p.ln_dim > 0 && !p.row_map && ((uintptr_t)p.ln_stats & 15) == 0));
   hipStream_t s = (hipStream_t)stream;
@@ -801,9 +806,9 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     if (ext && v == 10) { v = 0; gm = 1; }
   }
   if (p.stats_out) {      // row statistics are per wave-tile chunk: the split output only, whole chunks only
-    const bool pp3 = v == 45 && !p.ln_stats && !p.col_scale && !p.row_map && p.res_hi && p.act == INK_ACT_NONE;
+    const bool pp3 = (v == 45 && !p.ln_stats && !p.col_scale && !p.row_map && p.res_hi && p.act == INK_ACT_NONE) || v == 63;
     const int chunk = pp3 ? 80 : 64;
-    INK_CHECK_ARG(p.c_f16 == 2 && p.N % chunk == 0 && p.stats_parts == p.N / chunk && g_variant < 0);
+    INK_CHECK_ARG(p.c_f16 == 2 && p.N % chunk == 0 && p.stats_parts == p.N / chunk && (g_variant < 0 || v == 63));
   }
   // Production variants: 0 / 32 (128x128 tiles, K step 64 / 32), 10 (16-wave 256x256), 45 (ping-pong 256x320).
   // 40/42/47/53/16/12/14/11 are alternative CORRECT tilings kept for tools/gemm_sweep.py (ink_gemm_set_variant).
@@ -845,6 +850,9 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     case 50: return launch_gemm_pp<4, 5, 9>(p, s, gm);                  // ... without MFMA
     case 51: return launch_gemm_pp<4, 5, 11>(p, s, gm);                 // ... pure DMA stream
     case 52: return launch_gemm_pp<4, 5, 15>(p, s, gm);                 // ... pure DMA stream, all L2 hits
+    case 61: return launch_gemm_pp<4, 5, 8, true, 1>(p, s, gm);         // per-workgroup timeline of the ABI-4 forms
+    case 62: return launch_gemm_pp<4, 5, 8, true, 2>(p, s, gm);         //   (stamps leave through col_scale)
+    case 63: return launch_gemm_pp<4, 5, 8, true, 3>(p, s, gm);
 #endif
     default: return launch_gemm<128, 128, 64, 2, 2, 2, 0, true>(p, s);  // variant 0
   }

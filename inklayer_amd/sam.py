@@ -88,12 +88,14 @@ class SamEngine:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[SamConfig] = None,
                  device: str | torch.device = "cuda", max_batch: int = 1, precise_tail: bool = True,
-                 ln_fold: bool = True, bias_correction: bool = True):
+                 ln_fold: bool = False, bias_correction: bool = True):
         """precise_tail=True (the product setting): neck + decoder on split-f16 operands.  False keeps the plain
         f16 tail of round 1 (faster by a few %, mask IoU 0.998 instead of >= 0.999; kept for A/B measurements).
-        ln_fold=True (the product setting): the residual stream of the 32 blocks lives as two f16 planes (hi + lo), the
-        hi plane is the operand of qkv / lin1 and both LayerNorms are folded into those projections - no LayerNorm
-        kernel and no conversion pass ever reads the stream.  False: f32 stream + layernorm_rows (rounds 1-2; A/B).
+        ln_fold=True (built and parity-tested in round 3, NOT the product setting): the residual stream of the 32 blocks
+        lives as two f16 planes (hi + lo), the hi plane is the operand of qkv / lin1 and both LayerNorms are folded into
+        those projections - no LayerNorm kernel ever reads the stream.  Measured slower than what it removes (DESIGN.md
+        §7: the split residual preload and the fold's prologue / epilogue cost 275 us per block against 90 us of
+        LayerNorm kernels), so the product keeps the f32 stream + layernorm_rows (False).
         bias_correction=True (the product setting): the biases of the 4 x 32 block projections absorb the EXPECTED error
         of rounding their weights to f16 (see _calibrate_bias_correction)."""
         cfg = cfg or SamConfig()
