@@ -243,10 +243,11 @@ class SamEngine:
                 W32 = sd[p + lin + ".weight"].detach().to(self.dev, torch.float32)
                 if nrm is not None and self.ln_fold:
                     W32 = W32 * w[f"b{i}.{nrm}.weight"][None, :]
-                    w16, bias = w[f"b{i}.{lin}.w_ln"], w[f"b{i}.{lin}.bias_ln"]
+                    w16, bkey = w[f"b{i}.{lin}.w_ln"], f"b{i}.{lin}.bias_ln"
                 else:
-                    w16, bias = w[f"b{i}.{lin}.weight"], w[f"b{i}.{lin}.bias"]
-                bias += ((W32 - w16.float()).double() @ means[f"b{i}.{lin}"].double()).float()
+                    w16, bkey = w[f"b{i}.{lin}.weight"], f"b{i}.{lin}.bias"
+                # a NEW tensor: w[bkey] may share storage with the caller's state dict, which must stay untouched
+                w[bkey] = (w[bkey].double() + (W32 - w16.float()).double() @ means[f"b{i}.{lin}"].double()).float().contiguous()
 
     def _pack_split(self, sd) -> None:
         """Split-f16 weight copies [N, 3K] (ops.split_weight) of the neck / decoder matrices, keyed '<name>.ws'."""

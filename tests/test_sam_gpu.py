@@ -241,3 +241,26 @@ def test_postprocess_packed_path_matches_oracle(dev, small_vith, input_hw, orig_
     assert (m.cpu().bool() != (ref_logits > 0)).float().mean().item() < 1e-5
     m2 = ops.sam_postprocess(low[:, 0].contiguous().to(dev), 1024, input_hw, orig_hw, 0.0, False)
     assert torch.equal(m2, m)
+
+
+@torch.no_grad()
+def test_engine_leaves_the_state_dict_untouched_and_bias_correction_helps(dev):
+    """The load-time bias correction (SamEngine._calibrate_bias_correction) writes NEW bias tensors - the caller's state
+    dict (which may share storage with the engine's f32 parameters) is not modified - and it lowers the error of the
+    block stack on a sketch (depth 4 here; full depth: tests/test_full_depth_gpu.py)."""
+    from oracle import sam_ref
+    from inklayer_amd import sam, synthetic, weights_init
+    oc, ec = _cfgs()
+    sd = weights_init.random_sam_state_dict(ec, dev, 7)                 # device tensors: the engine may alias them
+    before = {k: v.clone() for k, v in sd.items()}
+    eng = sam.SamEngine(sd, ec, dev)
+    assert all(torch.equal(v, before[k]) for k, v in sd.items())
+    plain = sam.SamEngine(sd, ec, dev, bias_correction=False)
+    img = synthetic.synthetic_sketch(4)
+    x = sam_ref.preprocess(oc, torch.from_numpy(img.copy()).permute(2, 0, 1))[None]
+    ref = sam_ref.image_encoder({k: v.cpu() for k, v in sd.items()}, oc, x, upto=4)[0].reshape(4096, -1)
+    dimg = torch.from_numpy(img.copy()).to(dev)
+    e_corr = _rel(eng.encode([dimg], upto=4)[0], ref)[1]
+    e_plain = _rel(plain.encode([dimg], upto=4)[0], ref)[1]
+    print(f"4 blocks on a sketch: l2-rel {e_plain:.2e} plain f16 weights, {e_corr:.2e} with the bias correction")
+    assert e_corr < 0.85 * e_plain
