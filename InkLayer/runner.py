@@ -52,12 +52,29 @@ def _prepare_out_dir(input_path, out_base_dir):
     return out_dir, input_pil
 
 
+STAGE_S = None      # measurement hook: a dict here accumulates wall seconds per stage of finish_sketch
+
+
+def _tick(name, t0):
+    if STAGE_S is not None:
+        import time
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except ImportError:
+            pass
+        STAGE_S[name] = STAGE_S.get(name, 0.0) + time.perf_counter() - t0
+
+
 def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_intermediate=False, inpaint=False,
                   masks_dev=None):
     """Everything of run_inklayer_pipeline after the detector and the segmentor have answered (runner.py:35-101): the
     output tree of the detection stage, then the refinement stage.  Shared by the per-file entry point below and by the
     batched directory runner (inklayer_amd/batch_runner.py), so both write the same tree.  masks_dev (optional): the same
     masks as a uint8 0/1 [n, H, W] CUDA tensor when the caller still has them in HBM (saves the re-upload)."""
+    import time
+    t0 = time.perf_counter()
     boxes_int = [[int(v) for v in box] for box in boxes_tensor.tolist()]
     save_norm_bboxes(bboxes_list=boxes_int, scores_list=dino_out["scores"], input_pil=input_pil,
                      out_path=os.path.join(out_dir, "bboxes.json"))
@@ -68,6 +85,8 @@ def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_inter
     save_all([(np.asarray(m, dtype=bool), os.path.join(masks_dir, f"mask_{i}.png")) for i, m in enumerate(masks_np)]  # 1-bit, PIL mode "1"
              + [(colour_by_masks(rgb, masks_np), os.path.join(out_dir, "segmented_sketch.png")),
                 (_draw_boxes(input_pil, boxes_int), os.path.join(out_dir, "bboxes.png"))])
+    _tick("masks/ + detection visualisations (files)", t0)
+    t0 = time.perf_counter()
 
     # Refinement (runner.py:69-73).  Mask cleanup, sketch NMS, Depth-Anything-V2 and the refinement stage (depth order,
     # disjoint parsing, growth, unlabeled mask) run on the GPU with the cleaned masks staying IN HBM from stage to stage
@@ -83,10 +102,17 @@ def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_inter
     if cleaned is None:
         import numpy as _np
         cleaned = _np.zeros((0,) + input_pil.size[::-1], _np.uint8)
+    _tick("mask cleanup (GPU)", t0)
+    t0 = time.perf_counter()
     run_clean_masks_on_sketch_dir(out_dir, cleaned=cleaned)
+    _tick("masks_cleaned/ (D2H + files)", t0)
+    t0 = time.perf_counter()
     bbox_out_path = run_postprocess_boxes_on_sketch_dir(out_dir, sketch_iou_thresh=0.2, cleaned_masks=cleaned)
+    _tick("sketch NMS (GPU pair table + host loop + files)", t0)
+    t0 = time.perf_counter()
     from InkLayer.refinement.refiner import run_refinement_on_sketch_dir
     run_refinement_on_sketch_dir(out_dir, bbox_out_path, cleaned_masks=cleaned)
+    _tick("depth + refinement stage + masks_disjoint/ masks_final/ (files)", t0)
     if inpaint:
         print("Inpainting (diffusers) is not part of this build: skipped.")
     else:

@@ -35,6 +35,7 @@ def run_files(files: Sequence[str], out_base_dir: str, batch: int = 8, no_interm
     import InkLayer.runner as R
     import InkLayer.segmentor.sam as SEG
     pipe = pipe or _pipeline()
+    R.STAGE_S = {} if stage_s is not None else None
     if pipe.seg.max_batch < batch:
         pipe.seg._alloc(batch)
     outs: List[str] = []
@@ -62,4 +63,8 @@ def run_files(files: Sequence[str], out_base_dir: str, batch: int = 8, no_interm
             outs.append(R.finish_sketch(out_dir, pil, dino_out, r.boxes_pixel, [m[k] for k in range(m.shape[0])],
                                         no_intermediate=no_intermediate, masks_dev=r.masks))
         tick("tree + refinement (per file)", t0)
+    if stage_s is not None:
+        for k, v in R.STAGE_S.items():
+            stage_s["  of which " + k] = v
+        R.STAGE_S = None
     return outs
