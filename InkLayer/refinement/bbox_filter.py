@@ -50,11 +50,13 @@ def run_postprocess_boxes_on_sketch_dir(sketch_dir, sketch_iou_thresh=0.5, clean
     with open(target, "w") as fh:
         json.dump(kept, fh, indent=4)
     # bboxes_final.png: a plain visualisation (InkLayer/utils/visualization.py is outside the hot path)
-    canvas = Image.open(sketch_png).convert("RGB")
-    pen, (W, H) = ImageDraw.Draw(canvas), canvas.size
-    for x1, y1, x2, y2 in kept["bboxes"]:
-        pen.rectangle([x1 * W, y1 * H, x2 * W, y2 * H], outline=(220, 40, 40), width=2)
+    def _visual():
+        canvas = Image.open(sketch_png).convert("RGB")
+        pen, (W, H) = ImageDraw.Draw(canvas), canvas.size
+        for x1, y1, x2, y2 in kept["bboxes"]:
+            pen.rectangle([x1 * W, y1 * H, x2 * W, y2 * H], outline=(220, 40, 40), width=2)
+        return canvas
     from InkLayer.utils.io import save_all
-    save_all([(canvas, os.path.join(sketch_dir, "bboxes_final.png"))])
+    save_all([(_visual, os.path.join(sketch_dir, "bboxes_final.png"))], wait=None)
     print(f"sketch NMS kept {len(kept['bboxes'])} of {len(detections['bboxes'])} boxes -> {target}")
     return target

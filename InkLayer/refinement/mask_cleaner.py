@@ -70,6 +70,6 @@ def run_clean_masks_on_sketch_dir(sketch_dir, masks=None, cleaned=None):
     if hasattr(cleaned, "cpu"):
         cleaned = cleaned.cpu().numpy()
     from InkLayer.utils.io import save_all
-    save_all((np.ascontiguousarray(m), os.path.join(dst, f"mask_{i}.png")) for i, m in enumerate(cleaned))
+    save_all(((np.ascontiguousarray(m), os.path.join(dst, f"mask_{i}.png")) for i, m in enumerate(cleaned)), wait=None)
     print(f"cleaned {len(cleaned)} masks -> {dst}")
     return dst

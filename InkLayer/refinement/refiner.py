@@ -109,17 +109,17 @@ def run_refinement_on_sketch_dir(sketch_dir, bboxes_path, out_base_dir=None, cle
     shutil.rmtree(dis_dir, ignore_errors=True)
     os.makedirs(dis_dir, exist_ok=True)
     from InkLayer.utils.io import save_all
-    save_all((m.astype(np.uint8) * 255, f"{dis_dir}/mask_{i}.png") for i, m in enumerate(res.disjoint_masks()))
+    save_all(((m.astype(np.uint8) * 255, f"{dis_dir}/mask_{i}.png") for i, m in enumerate(res.disjoint_masks())), wait=None)
     out_dir = f"{out_base_dir}/masks_final"
     shutil.rmtree(out_dir, ignore_errors=True)
     os.makedirs(out_dir, exist_ok=True)
     final_masks = res.final_masks()
-    save_all(((np.asarray(m) > 0).astype(np.uint8) * 255, f"{out_dir}/mask_{i}.png") for i, m in enumerate(final_masks))
+    save_all((((np.asarray(m) > 0).astype(np.uint8) * 255, f"{out_dir}/mask_{i}.png") for i, m in enumerate(final_masks)), wait=None)
     depth_map = depth_dev.cpu().numpy()
     lo, hi = float(depth_map.min()), float(depth_map.max())             # cv2.normalize(NORM_MINMAX, 0..255)
     norm = (depth_map - lo) * (255.0 / (hi - lo)) if hi > lo else np.zeros_like(depth_map)
     from InkLayer.runner import colour_by_masks
-    save_all([(np.repeat(np.clip(norm, 0, 255).astype(np.uint8)[..., None], 3, axis=2), f"{out_base_dir}/depth_map.png"),
-              (colour_by_masks(rgb, final_masks), f"{out_base_dir}/segmented_sketch_final.png")])
+    save_all([(lambda: np.repeat(np.clip(norm, 0, 255).astype(np.uint8)[..., None], 3, axis=2), f"{out_base_dir}/depth_map.png"),
+              (lambda: colour_by_masks(rgb, final_masks), f"{out_base_dir}/segmented_sketch_final.png")], wait=None)
     print(f"Results saved to {out_dir}")
     return out_dir

@@ -10,7 +10,7 @@ from PIL import Image, ImageDraw
 
 from InkLayer.detector.gdino import run_ft_dino_on_sketch
 from InkLayer.segmentor.sam import run_SAM
-from InkLayer.utils.io import save_all
+from InkLayer.utils.io import flush, save_all
 from InkLayer.utils.processing import process_dino_output, save_norm_bboxes
 
 
@@ -68,12 +68,16 @@ def _tick(name, t0):
 
 
 def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_intermediate=False, inpaint=False,
-                  masks_dev=None):
+                  masks_dev=None, flush_files=True):
     """Everything of run_inklayer_pipeline after the detector and the segmentor have answered (runner.py:35-101): the
     output tree of the detection stage, then the refinement stage.  Shared by the per-file entry point below and by the
     batched directory runner (inklayer_amd/batch_runner.py), so both write the same tree.  masks_dev (optional): the same
-    masks as a uint8 0/1 [n, H, W] CUDA tensor when the caller still has them in HBM (saves the re-upload)."""
+    masks as a uint8 0/1 [n, H, W] CUDA tensor when the caller still has them in HBM (saves the re-upload).
+    flush_files=False: the PNG encoding of this sketch may still be running on the I/O threads when the call returns
+    (InkLayer.utils.io.flush() waits for it) - the batched runner overlaps it with the next sketch's GPU stages."""
     import time
+    import InkLayer.utils.io as _io
+    _io.DEFER = True            # the plugin functions below hand their PNGs to the I/O threads and return
     t0 = time.perf_counter()
     boxes_int = [[int(v) for v in box] for box in boxes_tensor.tolist()]
     save_norm_bboxes(bboxes_list=boxes_int, scores_list=dino_out["scores"], input_pil=input_pil,
@@ -83,8 +87,8 @@ def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_inter
     os.makedirs(masks_dir, exist_ok=True)
     rgb = np.asarray(input_pil)
     save_all([(np.asarray(m, dtype=bool), os.path.join(masks_dir, f"mask_{i}.png")) for i, m in enumerate(masks_np)]  # 1-bit, PIL mode "1"
-             + [(colour_by_masks(rgb, masks_np), os.path.join(out_dir, "segmented_sketch.png")),
-                (_draw_boxes(input_pil, boxes_int), os.path.join(out_dir, "bboxes.png"))])
+             + [(lambda: colour_by_masks(rgb, masks_np), os.path.join(out_dir, "segmented_sketch.png")),
+                (lambda: _draw_boxes(input_pil, boxes_int), os.path.join(out_dir, "bboxes.png"))], wait=False)
     _tick("masks/ + detection visualisations (files)", t0)
     t0 = time.perf_counter()
 
@@ -117,7 +121,11 @@ def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_inter
         print("Inpainting (diffusers) is not part of this build: skipped.")
     else:
         print("Skipping inpainting step as 'inpaint' is set to False.")
+    _io.DEFER = False
+    if flush_files:
+        flush()
     if no_intermediate:
+        flush()
         keep = {"masks_final", "complete_layers", "complete_layers_rgba", "bboxes_final.json",
                 "bboxes_final.png", "segmented_sketch_final.png", "depth_map.png", "input.png"}
         for item in os.listdir(out_dir):

@@ -38,13 +38,39 @@ def write_png(path, a, level: int = 1) -> None:
         fh.write(data)
 
 
-def save_all(jobs) -> None:
-    """(array or PIL image, path) pairs -> PNG files, encoded on up to 8 threads."""
-    jobs = [(np.asarray(im), path) for im, path in jobs]
-    if len(jobs) <= 1:
-        for a, path in jobs:
-            write_png(path, a)
-        return
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-        list(ex.map(lambda j: write_png(j[1], j[0]), jobs))
+_POOL = None
+_PENDING = []
+DEFER = False       # set by InkLayer.runner.finish_sketch: save_all(wait=None) then returns before the files are written
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=8)
+    return _POOL
+
+
+def _write(job):
+    im, path = job
+    write_png(path, np.asarray(im() if callable(im) else im))
+
+
+def save_all(jobs, wait=True) -> None:
+    """(array | PIL image | callable returning one, path) pairs -> PNG files, encoded on up to 8 threads.
+    wait=False: returns at once; `flush()` waits for everything submitted so far (the runner flushes before it returns,
+    so the host-side encoding of one sketch's files overlaps with the GPU stages that follow).  wait=None: deferred only
+    inside the runner (DEFER), synchronous when a plugin function is called on its own."""
+    if wait is None:
+        wait = not DEFER
+    futs = [_pool().submit(_write, j) for j in jobs]
+    if wait:
+        for f in futs:
+            f.result()
+    else:
+        _PENDING.extend(futs)
+
+
+def flush() -> None:
+    while _PENDING:
+        _PENDING.pop().result()

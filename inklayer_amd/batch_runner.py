@@ -61,8 +61,12 @@ def run_files(files: Sequence[str], out_base_dir: str, batch: int = 8, no_interm
             dino_out = {"bboxes": r.boxes_xyxy_norm.tolist(), "scores": r.scores.tolist(),
                         "labels": ["object"] * len(r.scores)}
             outs.append(R.finish_sketch(out_dir, pil, dino_out, r.boxes_pixel, [m[k] for k in range(m.shape[0])],
-                                        no_intermediate=no_intermediate, masks_dev=r.masks))
+                                        no_intermediate=no_intermediate, masks_dev=r.masks, flush_files=False))
         tick("tree + refinement (per file)", t0)
+    t0 = time.perf_counter()
+    from InkLayer.utils.io import flush
+    flush()                                         # every file of every sketch is on disk when the call returns
+    tick("waiting for the PNG encoders", t0)
     if stage_s is not None:
         for k, v in R.STAGE_S.items():
             stage_s["  of which " + k] = v
