@@ -78,50 +78,52 @@ def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_inter
     import time
     import InkLayer.utils.io as _io
     _io.DEFER = True            # the plugin functions below hand their PNGs to the I/O threads and return
-    t0 = time.perf_counter()
-    boxes_int = [[int(v) for v in box] for box in boxes_tensor.tolist()]
-    save_norm_bboxes(bboxes_list=boxes_int, scores_list=dino_out["scores"], input_pil=input_pil,
-                     out_path=os.path.join(out_dir, "bboxes.json"))
-    import numpy as np
-    masks_dir = os.path.join(out_dir, "masks")
-    os.makedirs(masks_dir, exist_ok=True)
-    rgb = np.asarray(input_pil)
-    save_all([(np.asarray(m, dtype=bool), os.path.join(masks_dir, f"mask_{i}.png")) for i, m in enumerate(masks_np)]  # 1-bit, PIL mode "1"
-             + [(lambda: colour_by_masks(rgb, masks_np), os.path.join(out_dir, "segmented_sketch.png")),
-                (lambda: _draw_boxes(input_pil, boxes_int), os.path.join(out_dir, "bboxes.png"))], wait=False)
-    _tick("masks/ + detection visualisations (files)", t0)
-    t0 = time.perf_counter()
+    try:
+        t0 = time.perf_counter()
+        boxes_int = [[int(v) for v in box] for box in boxes_tensor.tolist()]
+        save_norm_bboxes(bboxes_list=boxes_int, scores_list=dino_out["scores"], input_pil=input_pil,
+                         out_path=os.path.join(out_dir, "bboxes.json"))
+        import numpy as np
+        masks_dir = os.path.join(out_dir, "masks")
+        os.makedirs(masks_dir, exist_ok=True)
+        rgb = np.asarray(input_pil)
+        save_all([(np.asarray(m, dtype=bool), os.path.join(masks_dir, f"mask_{i}.png")) for i, m in enumerate(masks_np)]  # 1-bit, PIL mode "1"
+                 + [(lambda: colour_by_masks(rgb, masks_np), os.path.join(out_dir, "segmented_sketch.png")),
+                    (lambda: _draw_boxes(input_pil, boxes_int), os.path.join(out_dir, "bboxes.png"))], wait=False)
+        _tick("masks/ + detection visualisations (files)", t0)
+        t0 = time.perf_counter()
 
-    # Refinement (runner.py:69-73).  Mask cleanup, sketch NMS, Depth-Anything-V2 and the refinement stage (depth order,
-    # disjoint parsing, growth, unlabeled mask) run on the GPU with the cleaned masks staying IN HBM from stage to stage
-    # (the files masks_cleaned/, bboxes_final.json, masks_disjoint/, masks_final/ are still written: they are part of the
-    # output tree); only the stroke thinning and the raster-order box assignment are host code (inklayer_amd/refine_stage.py).
-    from InkLayer.refinement.mask_cleaner import run_clean_masks_on_sketch_dir, clean_masks_on_device
-    from InkLayer.refinement.bbox_filter import run_postprocess_boxes_on_sketch_dir
-    if masks_dev is not None and len(masks_np):
-        from InkLayer.refinement.mask_cleaner import clean_device_masks
-        cleaned = clean_device_masks(masks_dev)
-    else:
-        cleaned = clean_masks_on_device(masks_np)
-    if cleaned is None:
-        import numpy as _np
-        cleaned = _np.zeros((0,) + input_pil.size[::-1], _np.uint8)
-    _tick("mask cleanup (GPU)", t0)
-    t0 = time.perf_counter()
-    run_clean_masks_on_sketch_dir(out_dir, cleaned=cleaned)
-    _tick("masks_cleaned/ (D2H + files)", t0)
-    t0 = time.perf_counter()
-    bbox_out_path = run_postprocess_boxes_on_sketch_dir(out_dir, sketch_iou_thresh=0.2, cleaned_masks=cleaned)
-    _tick("sketch NMS (GPU pair table + host loop + files)", t0)
-    t0 = time.perf_counter()
-    from InkLayer.refinement.refiner import run_refinement_on_sketch_dir
-    run_refinement_on_sketch_dir(out_dir, bbox_out_path, cleaned_masks=cleaned)
-    _tick("depth + refinement stage + masks_disjoint/ masks_final/ (files)", t0)
-    if inpaint:
-        print("Inpainting (diffusers) is not part of this build: skipped.")
-    else:
-        print("Skipping inpainting step as 'inpaint' is set to False.")
-    _io.DEFER = False
+        # Refinement (runner.py:69-73).  Mask cleanup, sketch NMS, Depth-Anything-V2 and the refinement stage (depth order,
+        # disjoint parsing, growth, unlabeled mask) run on the GPU with the cleaned masks staying IN HBM from stage to stage
+        # (the files masks_cleaned/, bboxes_final.json, masks_disjoint/, masks_final/ are still written: they are part of the
+        # output tree); only the stroke thinning and the raster-order box assignment are host code (inklayer_amd/refine_stage.py).
+        from InkLayer.refinement.mask_cleaner import run_clean_masks_on_sketch_dir, clean_masks_on_device
+        from InkLayer.refinement.bbox_filter import run_postprocess_boxes_on_sketch_dir
+        if masks_dev is not None and len(masks_np):
+            from InkLayer.refinement.mask_cleaner import clean_device_masks
+            cleaned = clean_device_masks(masks_dev)
+        else:
+            cleaned = clean_masks_on_device(masks_np)
+        if cleaned is None:
+            import numpy as _np
+            cleaned = _np.zeros((0,) + input_pil.size[::-1], _np.uint8)
+        _tick("mask cleanup (GPU)", t0)
+        t0 = time.perf_counter()
+        run_clean_masks_on_sketch_dir(out_dir, cleaned=cleaned)
+        _tick("masks_cleaned/ (D2H + files)", t0)
+        t0 = time.perf_counter()
+        bbox_out_path = run_postprocess_boxes_on_sketch_dir(out_dir, sketch_iou_thresh=0.2, cleaned_masks=cleaned)
+        _tick("sketch NMS (GPU pair table + host loop + files)", t0)
+        t0 = time.perf_counter()
+        from InkLayer.refinement.refiner import run_refinement_on_sketch_dir
+        run_refinement_on_sketch_dir(out_dir, bbox_out_path, cleaned_masks=cleaned)
+        _tick("depth + refinement stage + masks_disjoint/ masks_final/ (files)", t0)
+        if inpaint:
+            print("Inpainting (diffusers) is not part of this build: skipped.")
+        else:
+            print("Skipping inpainting step as 'inpaint' is set to False.")
+    finally:
+        _io.DEFER = False
     if flush_files:
         flush()
     if no_intermediate:

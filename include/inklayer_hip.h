@@ -314,6 +314,23 @@ int ink_attn_fewq(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
                   const int32_t* q_batch_rows, const int32_t* kv_batch_rows, const float* k_add, int32_t io_f32, void* O,
                   int64_t ldo, void* stream);
 
+/* Column (max, sum-exp) over the S rows of B score matrices [S, HT] f32 (HT <= 16): stats f32 [B, HT, 2];
+ * part_ws f32 [B * ceil(S / 512) * HT * 2].  The text-side softmax statistics of the fusion layer. */
+int ink_biattn_colstats(const float* scores, int32_t B, int32_t S, int32_t HT, float* part_ws, float* stats, void* stream);
+
+/* BiAttentionBlock (GD/.../fuse_modules.py:146-295) with the <= 4 text tokens of InkLayer's fixed caption FOLDED through
+ * it: the image tokens v f32 [B*S, 256] are updated IN PLACE to  LN_v(v) + gamma_v * out_v_proj(attention over text)  and
+ * out_l f16 [B*T, 1024] receives the text-side attention output (operand of out_l_proj), without ever forming the per-token
+ * q / value_v projections (256 -> 2 x 1024) or the 1024 -> 256 image output projection - see csrc/fusion_fold.hip for
+ * the algebra.  text_k / text_vl: f32 [B*T, >= 1024] (row stride ld_text) = l_proj / values_l_proj of LN_l(l);
+ * Wq / Wvv f16 [1024, 256] (v_proj / values_v_proj weights), bq / bvv f32 [1024]; Wo f16 [256, 1024], bo f32 [256]
+ * (out_v_proj); scale = 256^-0.5.  ws: f32[ink_fusion_fold_workspace(B, S)].  S <= 32768. */
+int ink_fusion_fold_workspace(int32_t B, int32_t S, int64_t* out_floats);
+int ink_fusion_fold(float* v_f32, int32_t B, int32_t S, const float* lnv_g, const float* lnv_b, float eps,
+                    const float* text_k_f32, const float* text_vl_f32, int64_t ld_text, int32_t T, const void* Wq_f16,
+                    const float* bq, const void* Wvv_f16, const float* bvv, const void* Wo_f16, const float* bo,
+                    const float* gamma_v, float scale, float* ws, void* out_l_f16, void* stream);
+
 /* Two-stage query selection (transformer.py:293-300): indices of the K largest max_t logits[b,s,t],
  * descending, ties -> lower index.  logits f32 [B,S,T]; out_idx int32 [B,K].  S <= 16384 is one LDS
  * bitonic sort per image; larger S (800x1333 inputs give 22223 tokens) sorts ceil(S/16384) equal chunks and

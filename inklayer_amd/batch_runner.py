@@ -54,7 +54,7 @@ def run_files(files: Sequence[str], out_base_dir: str, batch: int = 8, no_interm
         tick("decode + input.png", t0)
         t0 = time.perf_counter()
         results = pipe.run_batch(images, top_n=top_n)                           # threshold path by default, as the plugin
-        masks_h = [r.masks.cpu().numpy().astype(bool) for r in results]
+        masks_h = [r.masks.cpu().numpy().view(np.bool_) for r in results]      # 0 / 1 bytes: a zero-copy bool view
         tick("detector + segmentor (batched hot path)", t0)
         t0 = time.perf_counter()
         for (out_dir, pil), r, m in zip(prepared, results, masks_h):

@@ -828,6 +828,18 @@ extern "C" int ink_biattn_fusion(const void* QV_f16, const void* KL_f16, int32_t
   return ink_launch_status();
 }
 
+// column (max, sum-exp) over the S rows of every image's [S, HT] score matrix (the text-side softmax statistics), also
+// used by the folded fusion layer (fusion_fold.hip).  part_ws: B * ceil(S / 512) * HT * 2 floats.
+extern "C" int ink_biattn_colstats(const float* scores, int32_t B, int32_t S, int32_t HT, float* part_ws, float* stats,
+                                   void* stream) {
+  INK_CHECK_ARG(scores && part_ws && stats && B > 0 && S > 0 && HT > 0 && HT <= 16);
+  hipStream_t s = (hipStream_t)stream;
+  const int rows_cs = 512, ncs = (S + rows_cs - 1) / rows_cs;
+  hipLaunchKernelGGL(biattn_colstats_partial_kernel, dim3(ncs, B), dim3(256), 0, s, scores, S, HT, rows_cs, part_ws);
+  hipLaunchKernelGGL(biattn_colstats_combine_kernel, dim3(B), dim3(64), 0, s, (const float*)part_ws, ncs, HT, stats);
+  return ink_launch_status();
+}
+
 extern "C" int ink_attn_fewkeys(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V,
                                 int64_t ldv, int32_t B, int32_t n_q, int32_t n_k, int32_t n_heads,
                                 int32_t head_dim, float scale, const uint8_t* blocked,

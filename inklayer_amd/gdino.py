@@ -214,6 +214,8 @@ def clean_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 
 class GDinoEngine:
+    fold_fusion = True       # the caption's tokens folded through the fusion layers (csrc/fusion_fold.hip); False: rounds 1-2 path
+
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[GDinoConfig] = None,
                  device: str | torch.device = "cuda", encoded_text: Optional[torch.Tensor] = None,
                  token_ids: Sequence[int] = DEFAULT_TOKEN_IDS):
@@ -478,15 +480,23 @@ class GDinoEngine:
         for i in range(cfg.enc_layers):
             d = f"e{i}"
             # --- BiAttentionBlock (fuse_modules.py:286-295): residual from the NORMALISED v / l
-            vn = torch.empty_like(src)
-            ops.layernorm_rows(src, w[d + ".fu.lnv.w"], w[d + ".fu.lnv.b"], 1e-5, out=vn, out2=s16)
             ln32 = torch.empty_like(text)
             l16 = torch.empty(text.shape, device=dev, dtype=F16)
             ops.layernorm_rows(text, w[d + ".fu.lnl.w"], w[d + ".fu.lnl.b"], 1e-5, out=ln32, out2=l16)
-            qv = ops.gemm(s16, w[d + ".fu.qv.w"], w[d + ".fu.qv.b"], out_dtype=F16)
-            kl = ops.gemm(l16, w[d + ".fu.kl.w"], w[d + ".fu.kl.b"], out_dtype=F16)
-            ov, ol = ops.biattn_fusion(qv, kl, B, S, T, 256 ** -0.5)
-            src = ops.gemm(ov, w[d + ".fu.outv.w"], w[d + ".fu.outv.b"], col_scale=w[d + ".fu.gv"], residual=vn, out=vn)
+            if self.fold_fusion and T <= 4:
+                # the caption's <= 4 tokens folded through the fusion layer (csrc/fusion_fold.hip): no per-token
+                # 256 -> 2048 projection, no 1024 -> 256 image output projection, f32 throughout
+                kl = ops.gemm(l16, w[d + ".fu.kl.w"], w[d + ".fu.kl.b"])
+                ol = ops.fusion_fold(src, B, S, w[d + ".fu.lnv.w"], w[d + ".fu.lnv.b"], 1e-5, kl, T, w[d + ".fu.qv.w"],
+                                     w[d + ".fu.qv.b"], w[d + ".fu.outv.w"], w[d + ".fu.outv.b"], w[d + ".fu.gv"],
+                                     256 ** -0.5)
+            else:
+                vn = torch.empty_like(src)
+                ops.layernorm_rows(src, w[d + ".fu.lnv.w"], w[d + ".fu.lnv.b"], 1e-5, out=vn, out2=s16)
+                qv = ops.gemm(s16, w[d + ".fu.qv.w"], w[d + ".fu.qv.b"], out_dtype=F16)
+                kl = ops.gemm(l16, w[d + ".fu.kl.w"], w[d + ".fu.kl.b"], out_dtype=F16)
+                ov, ol = ops.biattn_fusion(qv, kl, B, S, T, 256 ** -0.5)
+                src = ops.gemm(ov, w[d + ".fu.outv.w"], w[d + ".fu.outv.b"], col_scale=w[d + ".fu.gv"], residual=vn, out=vn)
             text = ops.gemm(ol, w[d + ".fu.outl.w"], w[d + ".fu.outl.b"], col_scale=w[d + ".fu.gl"], residual=ln32)
             # --- text enhancer (transformer_vanilla.py:101-123), 4 heads x 64, block-diagonal mask
             qk = ops.gemm(ops.add_cvt_f16(text, self.pos_text), w[d + ".txt.qk.w"], w[d + ".txt.qk.b"], out_dtype=F16)

@@ -548,6 +548,28 @@ def biattn_fusion(qv16: torch.Tensor, kl16: torch.Tensor, B: int, S: int, T: int
     return out_v, out_l
 
 
+def fusion_fold(v: torch.Tensor, B: int, S: int, lnv_g: torch.Tensor, lnv_b: torch.Tensor, eps: float,
+                text_kv: torch.Tensor, T: int, Wqv: torch.Tensor, bqv: torch.Tensor, Wo: torch.Tensor, bo: torch.Tensor,
+                gamma_v: torch.Tensor, scale: float) -> torch.Tensor:
+    """BiAttentionBlock with the <= 4 caption tokens folded through it (csrc/fusion_fold.hip): v f32 [B*S, 256] is
+    updated IN PLACE; returns the text-side attention output f16 [B*T, 1024].  text_kv: f32 [B*T, 2048] =
+    [l_proj | values_l_proj] of LN_l(l); Wqv f16 [2048, 256] / bqv f32 [2048] = [v_proj ; values_v_proj]."""
+    assert v.dtype == F32 and v.is_contiguous() and tuple(v.shape) == (B * S, 256)
+    assert text_kv.dtype == F32 and text_kv.stride(1) == 1 and tuple(text_kv.shape) == (B * T, 2048)
+    assert Wqv.dtype == F16 and Wqv.is_contiguous() and tuple(Wqv.shape) == (2048, 256) and bqv.dtype == F32
+    assert Wo.dtype == F16 and Wo.is_contiguous() and tuple(Wo.shape) == (256, 1024)
+    need = C.c_int64(0)
+    check(_lib.lib().ink_fusion_fold_workspace(B, S, C.byref(need)), "ink_fusion_fold_workspace")
+    ws = torch.empty(need.value, device=v.device, dtype=F32)
+    out_l = torch.empty((B * T, 1024), device=v.device, dtype=F16)
+    check(_lib.lib().ink_fusion_fold(v.data_ptr(), B, S, lnv_g.data_ptr(), lnv_b.data_ptr(), eps, text_kv.data_ptr(),
+                                     text_kv[:, 1024:].data_ptr(), text_kv.stride(0), T, Wqv.data_ptr(), bqv.data_ptr(),
+                                     Wqv[1024:].data_ptr(), bqv[1024:].data_ptr(), Wo.data_ptr(), bo.data_ptr(),
+                                     gamma_v.data_ptr(), scale, ws.data_ptr(), out_l.data_ptr(), _stream()),
+          "ink_fusion_fold")
+    return out_l
+
+
 def attn_fewkeys(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, B: int, n_heads: int, head_dim: int,
                  scale: float, blocked: Optional[torch.Tensor] = None, n_q: Optional[int] = None,
                  q_batch_rows: Optional[torch.Tensor] = None, q_add: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -368,3 +368,40 @@ def test_detector_caches_are_bounded(dev, small_dino):
     print("allocated MB per size:", [round(m / 2 ** 20, 1) for m in mem])
     assert growth_late < 0.5 * max(growth_early, 1 << 20) + (64 << 20)      # sizes differ a little; no linear growth
     eng._graphs.clear(); eng._seen.clear()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("T", [4, 3])
+def test_folded_fusion_layer_equals_the_full_one(dev, T):
+    """ops.fusion_fold (csrc/fusion_fold.hip: the caption's tokens folded through BiAttentionBlock, no per-token
+    256 -> 2048 projection) against the layer computed the reference's way in float64 (fuse_modules.py:146-295): image
+    update in place, text-side attention output."""
+    from inklayer_amd import ops
+    g = torch.Generator().manual_seed(11 + T)
+    B, S, E, D = 2, 1337, 1024, 256
+    v = torch.randn(B * S, D, generator=g) * 1.3 + 0.2
+    kl = torch.randn(B * T, 2 * E, generator=g) * 0.7                    # [l_proj | values_l_proj] of LN_l(l)
+    Wqv = (torch.randn(2 * E, D, generator=g) / D ** 0.5).half()
+    bqv = 0.1 * torch.randn(2 * E, generator=g)
+    Wo = (torch.randn(D, E, generator=g) / E ** 0.5).half()
+    bo = 0.1 * torch.randn(D, generator=g)
+    lng, lnb = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    gam = 0.2 + 0.1 * torch.randn(D, generator=g)
+    scale = 256 ** -0.5
+    vd = v.to(dev).clone()
+    out_l = ops.fusion_fold(vd, B, S, lng.to(dev), lnb.to(dev), 1e-5, kl.to(dev), T, Wqv.to(dev), bqv.to(dev), Wo.to(dev),
+                            bo.to(dev), gam.to(dev), scale)
+    # the reference's order of operations, float64
+    vn = torch.nn.functional.layer_norm(v.double(), (D,), lng.double(), lnb.double(), 1e-5).view(B, S, D)
+    q = (vn @ Wqv[:E].double().t() + bqv[:E].double()) * scale
+    vv = vn @ Wqv[E:].double().t() + bqv[E:].double()
+    k, vl = kl[:, :E].double().view(B, T, E), kl[:, E:].double().view(B, T, E)
+    sp = lambda t: t.view(B, -1, 4, 256).transpose(1, 2)                  # [B, 4, n, 256]
+    aw = sp(q) @ sp(k).transpose(-1, -2)                                  # [B, 4, S, T]
+    ov = (aw.softmax(-1) @ sp(vl)).transpose(1, 2).reshape(B, S, E)
+    ol = (aw.transpose(-1, -2).softmax(-1) @ sp(vv)).transpose(1, 2).reshape(B * T, E)
+    want_v = (vn + gam.double() * (ov @ Wo.double().t() + bo.double())).view(B * S, D)
+    ev = ((vd.double().cpu() - want_v).abs().max() / want_v.abs().max()).item()
+    el = ((out_l.double().cpu() - ol).abs().max() / ol.abs().max()).item()
+    print(f"T={T}: image update max-rel {ev:.2e}, text-side output max-rel {el:.2e} (f16 store)")
+    assert ev < 2e-5 and el < 1e-3
