@@ -93,16 +93,17 @@ __global__ __launch_bounds__(256) void fuse_prep_kernel(const float* __restrict_
 }
 
 // one wave per token: vn = LN(x) * g + be (written over x), scores[s, j] = vn . U[b, j] + c[b, j].
-// grid (ceil(S / 4 / TPW), B); a workgroup stages U[b] in LDS once and walks TPW tokens per wave.
-constexpr int TPW = 8;
+// grid (ceil(S / 4 / TPW), B); every wave keeps ITS four channels of the 16 U rows in registers (64 VGPRs: an LDS copy
+// costs 16 ds_read_b128 per token and made the kernel LDS-issue-bound) and walks TPW tokens.
+constexpr int TPW = 16;
 __global__ __launch_bounds__(256) void fuse_ln_scores_kernel(float* __restrict__ x, int S, const float* __restrict__ g,
                                                              const float* __restrict__ be, float eps,
                                                              const float* __restrict__ U, const float* __restrict__ c,
                                                              float* __restrict__ scores) {
-  __shared__ __attribute__((aligned(16))) float u[FJ * FD];
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < FJ * FD / 4; i += 256) ((f32x4*)u)[i] = ((const f32x4*)(U + (int64_t)b * FJ * FD))[i];
-  __syncthreads();
+  f32x4 u[FJ];
+#pragma unroll
+  for (int j = 0; j < FJ; ++j) u[j] = *(const f32x4*)(U + ((int64_t)b * FJ + j) * FD + lane * 4);
   const f32x4 gv = *(const f32x4*)(g + lane * 4), bv = *(const f32x4*)(be + lane * 4);
   const float cj = c[b * FJ + (lane >> 2)];
   const int s0 = (blockIdx.x * 4 + wave) * TPW;
@@ -117,10 +118,7 @@ __global__ __launch_bounds__(256) void fuse_ln_scores_kernel(float* __restrict__
     *(f32x4*)row = v;
     float part[16];
 #pragma unroll
-    for (int j = 0; j < FJ; ++j) {
-      const f32x4 uj = *(const f32x4*)(u + j * FD + lane * 4);
-      part[j] = (v[0] * uj[0] + v[1] * uj[1]) + (v[2] * uj[2] + v[3] * uj[3]);
-    }
+    for (int j = 0; j < FJ; ++j) part[j] = (v[0] * u[j][0] + v[1] * u[j][1]) + (v[2] * u[j][2] + v[3] * u[j][3]);
     const float sc = wave_reduce16(part, lane) + cj;
     if ((lane & 3) == 0) scores[((int64_t)b * S + s) * FJ + (lane >> 2)] = sc;
   }
@@ -128,17 +126,19 @@ __global__ __launch_bounds__(256) void fuse_ln_scores_kernel(float* __restrict__
 
 // one wave per token: p_v = softmax_t(scores[s, h, :]);  x[s] = vn[s] + gamma * (p_v Z[b] + bo)  (in place);
 // text side: w[j] = exp(scores[s, j] - max_j) (normalised later), partial[b, chunk, j, :] = sum over the workgroup's
-// tokens of w[j] vn[s].  grid (nchunk, B): the workgroup owns tokens [chunk * TOK, (chunk + 1) * TOK).
+// tokens of w[j] vn[s].  grid (nchunk, B): the workgroup owns tokens [chunk * TOK, (chunk + 1) * TOK).  Z rows live in
+// registers (the lane's four channels of the 16 rows), the 16 probabilities / weights of a token reach every lane as
+// scalars (v_readlane of the lane group that holds them) - no LDS in the token loop.
 __global__ __launch_bounds__(256) void fuse_apply_kernel(float* __restrict__ x, int S, int tok_per_wg,
                                                          const float* __restrict__ scores,
                                                          const float* __restrict__ stats, const float* __restrict__ Z,
                                                          const float* __restrict__ gamma, const float* __restrict__ bo,
                                                          float* __restrict__ partial) {
-  __shared__ __attribute__((aligned(16))) float z[FJ * FD];
-  __shared__ __attribute__((aligned(16))) float pw[4][2][FJ];          // per wave: p_v, w
+  __shared__ __attribute__((aligned(16))) float red[FJ * FD];
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < FJ * FD / 4; i += 256) ((f32x4*)z)[i] = ((const f32x4*)(Z + (int64_t)b * FJ * FD))[i];
-  __syncthreads();
+  f32x4 z[FJ];
+#pragma unroll
+  for (int q = 0; q < FJ; ++q) z[q] = *(const f32x4*)(Z + ((int64_t)b * FJ + q) * FD + lane * 4);
   const f32x4 gv = *(const f32x4*)(gamma + lane * 4), ov = *(const f32x4*)(bo + lane * 4);
   const int j = lane >> 2;
   const float cmax = stats[((int64_t)b * FJ + j) * 2];
@@ -154,50 +154,56 @@ __global__ __launch_bounds__(256) void fuse_apply_kernel(float* __restrict__ x, 
     const float e = expf(sc - mx);
     float sum = e + __shfl_xor(e, 4, 64);
     sum += __shfl_xor(sum, 8, 64);
-    if ((lane & 3) == 0) {
-      pw[wave][0][j] = e / sum;
-      pw[wave][1][j] = expf(sc - cmax);
-    }
+    const float pv = e / sum, wl = expf(sc - cmax);
     float* row = x + ((int64_t)b * S + s) * FD + lane * 4;
     const f32x4 v = *(const f32x4*)row;
     f32x4 o = ov;
 #pragma unroll
     for (int q = 0; q < FJ; ++q) {
-      const float p = pw[wave][0][q], w = pw[wave][1][q];    // (same wave wrote them: LDS is in order per wave)
-      const f32x4 zq = *(const f32x4*)(z + q * FD + lane * 4);
-      o += p * zq;
+      const float p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv), 4 * q));
+      const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), 4 * q));
+      o += p * z[q];
       acc[q] += w * v;
     }
     *(f32x4*)row = v + gv * o;
   }
-  // the four waves' accumulators -> one partial per workgroup (through the Z staging area, no longer needed)
-  __syncthreads();
+  // the four waves' accumulators -> one partial per workgroup
   for (int wv = 0; wv < 4; ++wv) {
     if (wave == wv) {
 #pragma unroll
       for (int q = 0; q < FJ; ++q) {
-        f32x4* dst = (f32x4*)(z + q * FD + lane * 4);
+        f32x4* dst = (f32x4*)(red + q * FD + lane * 4);
         *dst = wv == 0 ? acc[q] : *dst + acc[q];
       }
     }
     __syncthreads();
   }
   float* out = partial + ((int64_t)b * nchunk + chunk) * FJ * FD;
-  for (int i = threadIdx.x; i < FJ * FD / 4; i += 256) ((f32x4*)out)[i] = ((const f32x4*)z)[i];
+  for (int i = threadIdx.x; i < FJ * FD / 4; i += 256) ((f32x4*)out)[i] = ((const f32x4*)red)[i];
 }
 
 // m[b, j, :] = sum_chunk partial / sumexp_j;  out_l[b*T + t, h*256 + e] = Wvv[h*256 + e, :] . m[b, j, :] + bvv[h*256 + e]
-// (f16, the operand of the text-side output projection).  grid (16, B), 256 threads.
-__global__ __launch_bounds__(256) void fuse_text_kernel(const float* __restrict__ partial, int nchunk,
-                                                        const float* __restrict__ stats, const f16* __restrict__ Wvv,
-                                                        const float* __restrict__ bvv, int T, f16* __restrict__ out_l) {
+// (f16, the operand of the text-side output projection).  grid (16, B), 1024 threads: four thread groups sum every
+// fourth chunk each (the sum over ~100 chunks was one dependent chain per thread), combined in a fixed order.
+__global__ __launch_bounds__(1024) void fuse_text_kernel(const float* __restrict__ partial, int nchunk,
+                                                         const float* __restrict__ stats, const f16* __restrict__ Wvv,
+                                                         const float* __restrict__ bvv, int T, f16* __restrict__ out_l) {
+  __shared__ __attribute__((aligned(16))) float part[4][FD];
   __shared__ __attribute__((aligned(16))) float m[FD];
-  const int j = blockIdx.x, b = blockIdx.y, h = j >> 2, t = j & 3, i = threadIdx.x;
+  const int j = blockIdx.x, b = blockIdx.y, h = j >> 2, t = j & 3, i = threadIdx.x & 255, grp = threadIdx.x >> 8;
   if (t >= T) return;
-  float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += partial[(((int64_t)b * nchunk + c) * FJ + j) * FD + i];
-  m[i] = s / stats[((int64_t)b * FJ + j) * 2 + 1];
+  float s0 = 0.f, s1 = 0.f;
+  int c = grp;
+  for (; c + 4 < nchunk; c += 8) {
+    s0 += partial[(((int64_t)b * nchunk + c) * FJ + j) * FD + i];
+    s1 += partial[(((int64_t)b * nchunk + c + 4) * FJ + j) * FD + i];
+  }
+  if (c < nchunk) s0 += partial[(((int64_t)b * nchunk + c) * FJ + j) * FD + i];
+  part[grp][i] = s0 + s1;
   __syncthreads();
+  if (grp == 0) m[i] = ((part[0][i] + part[1][i]) + (part[2][i] + part[3][i])) / stats[((int64_t)b * FJ + j) * 2 + 1];
+  __syncthreads();
+  if (grp != 0) return;
   const f16* wr = Wvv + (int64_t)(h * FHD + i) * FD;
   float o = bvv[h * FHD + i];
   for (int d = 0; d < FD; d += 8) {
@@ -247,7 +253,7 @@ extern "C" int ink_fusion_fold(float* v_f32, int32_t B, int32_t S, const float* 
   if (ink_biattn_colstats(scores, B, S, FJ, cpart, stats, stream) != INK_OK) return INK_ERR_LAUNCH;
   hipLaunchKernelGGL(fuse_apply_kernel, dim3(nchunk, B), dim3(256), 0, s, v_f32, S, 128, (const float*)scores,
                      (const float*)stats, (const float*)Z, gamma_v, bo, partial);
-  hipLaunchKernelGGL(fuse_text_kernel, dim3(FJ, B), dim3(256), 0, s, (const float*)partial, nchunk, (const float*)stats,
+  hipLaunchKernelGGL(fuse_text_kernel, dim3(FJ, B), dim3(1024), 0, s, (const float*)partial, nchunk, (const float*)stats,
                      (const f16*)Wvv_f16, bvv, T, (f16*)out_l_f16);
   return ink_launch_status();
 }
