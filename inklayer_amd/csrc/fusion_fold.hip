@@ -106,10 +106,13 @@ __global__ __launch_bounds__(256) void fuse_ln_scores_kernel(float* __restrict__
   for (int j = 0; j < FJ; ++j) u[j] = *(const f32x4*)(U + ((int64_t)b * FJ + j) * FD + lane * 4);
   const f32x4 gv = *(const f32x4*)(g + lane * 4), bv = *(const f32x4*)(be + lane * 4);
   const float cj = c[b * FJ + (lane >> 2)];
-  const int s0 = (blockIdx.x * 4 + wave) * TPW;
-  for (int s = s0; s < s0 + TPW && s < S; ++s) {
+  const int s0 = (blockIdx.x * 4 + wave) * TPW, s1 = min(S, s0 + TPW);
+  if (s0 >= S) return;
+  f32x4 nxt = *(const f32x4*)(x + ((int64_t)b * S + s0) * FD + lane * 4);
+  for (int s = s0; s < s1; ++s) {
     float* row = x + ((int64_t)b * S + s) * FD + lane * 4;
-    f32x4 v = *(const f32x4*)row;
+    f32x4 v = nxt;
+    if (s + 1 < s1) nxt = *(const f32x4*)(row + FD);          // the next token's row is in flight during this one's math
     const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / FD);
     const f32x4 d = v - mean;
     const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / FD);
@@ -146,8 +149,19 @@ __global__ __launch_bounds__(256) void fuse_apply_kernel(float* __restrict__ x, 
 #pragma unroll
   for (int q = 0; q < FJ; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int s_lo = chunk * tok_per_wg, s_hi = min(S, s_lo + tok_per_wg);
+  float sc_n = 0.f;
+  f32x4 v_n = {0.f, 0.f, 0.f, 0.f};
+  if (s_lo + wave < s_hi) {
+    sc_n = scores[((int64_t)b * S + s_lo + wave) * FJ + j];
+    v_n = *(const f32x4*)(x + ((int64_t)b * S + s_lo + wave) * FD + lane * 4);
+  }
   for (int s = s_lo + wave; s < s_hi; s += 4) {
-    const float sc = scores[((int64_t)b * S + s) * FJ + j];
+    const float sc = sc_n;
+    const f32x4 v = v_n;
+    if (s + 4 < s_hi) {                                        // next token of this wave: in flight during the math below
+      sc_n = scores[((int64_t)b * S + s + 4) * FJ + j];
+      v_n = *(const f32x4*)(x + ((int64_t)b * S + s + 4) * FD + lane * 4);
+    }
     // softmax over the 4 text tokens of head j >> 2: the lanes that differ in bits 2, 3
     float mx = fmaxf(sc, __shfl_xor(sc, 4, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
@@ -156,7 +170,6 @@ __global__ __launch_bounds__(256) void fuse_apply_kernel(float* __restrict__ x, 
     sum += __shfl_xor(sum, 8, 64);
     const float pv = e / sum, wl = expf(sc - cmax);
     float* row = x + ((int64_t)b * S + s) * FD + lane * 4;
-    const f32x4 v = *(const f32x4*)row;
     f32x4 o = ov;
 #pragma unroll
     for (int q = 0; q < FJ; ++q) {
