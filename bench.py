@@ -309,7 +309,8 @@ def main():
         dom_var = max(by_var, key=lambda v: sum(t[1].elapsed_time(t[2]) for t in by_var[v]))
         dom = by_var[dom_var]
         traffic = None
-        pmc = ROOT / "profiles" / "r02_gemm_pmc.json"
+        pmcs = sorted((ROOT / "profiles").glob("r*_gemm_pmc.json"))     # the newest round's counters
+        pmc = pmcs[-1] if pmcs else ROOT / "profiles" / "none"
         if pmc.exists():      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
             pj = json.loads(pmc.read_text())
             if pj.get("variant") == dom_var:

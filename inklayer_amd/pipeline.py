@@ -71,6 +71,9 @@ class _NullCtx:
 class InkLayerPipeline:
     det_priority = 0
     seg_priority = 0
+    # which stage's launches the host queues first (the other stage's kernels cannot start before the host gets to
+    # them: ~600 detector launches are ~4 ms of host time, ~370 encoder launches ~2.5 ms); A/B'd by tools/stage_times.py
+    encoder_first = True
 
     def __init__(self, detector: gd.GDinoEngine, segmentor: sm.SamEngine, overlap: bool = True):
         self.det, self.seg = detector, segmentor
@@ -205,6 +208,10 @@ class InkLayerPipeline:
             cur = torch.cuda.current_stream(self.dev)
             self.s_det.wait_stream(cur)
             self.s_seg.wait_stream(cur)
+            emb = None
+            if self.encoder_first:
+                with torch.cuda.stream(self.s_seg):
+                    emb = self.seg.encode(sam_in, chan_reverse=True)
             with torch.cuda.stream(self.s_det):
                 logits, boxes = self.det.forward(det_in, allow_graph=False)   # graphs do not overlap across streams
                 both = torch.cat([logits, boxes], dim=-1)
@@ -212,8 +219,9 @@ class InkLayerPipeline:
                 host.copy_(both, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.s_det)
-            with torch.cuda.stream(self.s_seg):
-                emb = self.seg.encode(sam_in, chan_reverse=True)
+            if emb is None:
+                with torch.cuda.stream(self.s_seg):
+                    emb = self.seg.encode(sam_in, chan_reverse=True)
             ev.synchronize()                               # host needs the boxes; the encoder keeps running
             dets = self.det.postprocess(host, top_n=top_n)
             stream_ctx = torch.cuda.stream(self.s_seg)

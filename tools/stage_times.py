@@ -80,6 +80,12 @@ def main():
     both = pipeline.InkLayerPipeline(det, seg, overlap=True)
     med, mn = ev(lambda: both.run_uploaded(raw, top_n=a.boxes), a.iters)
     print(f"{'overlap step':12s} median {med:8.3f} ms   min {mn:8.3f} ms")
+    both.encoder_first = not both.encoder_first
+    med, mn = ev(lambda: both.run_uploaded(raw, top_n=a.boxes), a.iters)
+    print(f"{'overlap step, encoder_first=' + str(both.encoder_first):12s} median {med:8.3f} ms   min {mn:8.3f} ms")
+    both.encoder_first = not both.encoder_first
+    med, mn = ev(lambda: both.run_uploaded(raw, top_n=a.boxes), a.iters)
+    print(f"{'overlap step, encoder_first=' + str(both.encoder_first):12s} median {med:8.3f} ms   min {mn:8.3f} ms")
 
 
 if __name__ == "__main__":
