@@ -356,7 +356,9 @@ def main():
             "attention": attention_summary(atrace, roof_steps),
         }
         if world == 1 and not args.no_runner:
-            out["runner"] = runner_leg(pipe, args.batch, args.boxes)
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):     # the runner prints the reference's progress lines: the
+                out["runner"] = runner_leg(pipe, args.batch, args.boxes)   # bench's stdout is ONE JSON line
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.boxes)
         print(json.dumps(out), flush=True)

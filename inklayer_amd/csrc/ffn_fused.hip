@@ -1,0 +1,228 @@
+// Fused feed-forward block of GroundingDINO's deformable encoder layer for gfx950:
+//     out = LayerNorm(src + linear2(relu(linear1(src))))            d_model 256, d_ffn 2048
+// (DeformableTransformerEncoderLayer.forward_ffn + norm2, GD/models/GroundingDINO/transformer.py:780-799).
+// As two GEMMs the [rows, 2048] f16 hidden tensor is written and re-read (2 x 435 MB per layer at B = 8) and at
+// K = 256 / N = 256 the GEMM tiles are all prologue and epilogue (192 us each + 33 us LayerNorm).  Here the hidden
+// activations never leave the registers.
+//
+// One workgroup = 128 token rows = FOUR waves, one per SIMD with the whole 512-register file; a wave owns 32 rows.
+//   * d_ffn is walked in chunks of 64 hidden units.  Phase A: H^T[j, m] = W1c X^T (mfma_f32_32x32x16_f16, the wave's X
+//     fragments - 32 rows x 256 - stay in 64 registers for the whole tile), accumulators initialised with b1.
+//     relu + convert in registers: in the swapped form the lane (m = lane & 31, hh) holds 8 hidden units of ITS row per
+//     16-wide k-step, which IS the B-operand layout of phase B up to a fixed permutation of the hidden index inside
+//     16-blocks - a contraction index, so the permutation is applied to W2's columns when the weights are packed and
+//     costs nothing here (no shuffles, no LDS round trip).  Phase B: Y^T[n, m] += W2c H^T into 8 accumulator tiles
+//     (all 256 output columns of the wave's 32 rows: 128 registers), initialised with src + b2.
+//   * The weights are PRE-PACKED (ink_ffn256_pack) into the exact LDS image: per chunk 64 blocks of 1 KiB, each one
+//     MFMA A-operand (32 rows x 16 k, lane-linear).  Staging is a linear LDS-DMA copy (fully coalesced) and every
+//     fragment read is a lane-linear ds_read_b128 (conflict-free by construction).  Two 64-KiB buffers: chunk c + 1
+//     streams in while chunk c is computed; one barrier per chunk.  Only DMA is in flight inside the loop, so the one
+//     vmcnt(0) per chunk is exact.
+//   * Epilogue: a lane holds half of its row (128 values), the other half sits in lane ^ 32: LayerNorm statistics are
+//     in-lane sums + one cross-half exchange; rows leave through LDS (the weight buffers are free by then) as whole
+//     1-KiB rows.
+#include "common.h"
+#include "../../include/inklayer_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int C = 256, HC = 64, BM = 128;
+constexpr int BLK = 1024;                       // one A-operand block: 32 rows x 16 k of f16, lane-linear
+constexpr int W1_BLKS = (HC / 32) * (C / 16);   // 32: (jt, s)
+constexpr int W2_BLKS = (C / 32) * (HC / 16);   // 32: (nt, s)
+constexpr int CHUNK = (W1_BLKS + W2_BLKS) * BLK;   // 64 KiB per chunk of 64 hidden units
+constexpr int MAX_HID = 2048;
+constexpr int OROW = C * 4 + 16;                // epilogue staging row (f32) + pad
+constexpr int LDS_BYTES = 2 * CHUNK + MAX_HID * 4;
+static_assert(4 * 32 * OROW <= 2 * CHUNK, "epilogue staging fits the weight buffers");
+
+__device__ __forceinline__ f32x16 mfma32(const f16x8& a, const f16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// position p = 8 hh + e of a 16-wide k-step of phase B  <->  hidden unit (within the 16-block) the lane holds there
+__host__ __device__ constexpr int hid_perm(int p) { return (p & 7) < 4 ? 4 * (p >> 3) + (p & 7) : 8 + 4 * (p >> 3) + (p & 7) - 4; }
+
+__global__ __launch_bounds__(256) void ffn256_pack_kernel(const f16* __restrict__ W1, const f16* __restrict__ W2, int HID,
+                                                          f16* __restrict__ blob) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one 16-B piece of the blob
+  const int64_t total = (int64_t)(HID / HC) * (W1_BLKS + W2_BLKS) * 64;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  const int q = (int)((idx >> 6) % (W1_BLKS + W2_BLKS));
+  const int c = (int)((idx >> 6) / (W1_BLKS + W2_BLKS));
+  const int l = lane & 31, hh = lane >> 5;
+  f16x8 v;
+  if (q < W1_BLKS) {
+    const int jt = q / (C / 16), s = q % (C / 16);
+    v = *(const f16x8*)(W1 + (int64_t)(c * HC + 32 * jt + l) * C + 16 * s + 8 * hh);
+  } else {
+    const int nt = (q - W1_BLKS) / (HC / 16), s = (q - W1_BLKS) % (HC / 16);
+    const f16* src = W2 + (int64_t)(32 * nt + l) * HID + c * HC + 16 * s;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[hid_perm(8 * hh + e)];
+  }
+  *(f16x8*)(blob + idx * 8) = v;
+}
+
+__global__ __launch_bounds__(256) void ffn256_fused_kernel(const f16* __restrict__ X, int64_t ldx,
+                                                           const float* __restrict__ res, const f16* __restrict__ blob,
+                                                           const float* __restrict__ b1, const float* __restrict__ b2,
+                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                           float eps, int M, int HID, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* b1s = (float*)(smem + 2 * CHUNK);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l = lane & 31, hh = lane >> 5;
+  const int ntiles = (M + BM - 1) / BM;
+  const int m0 = xcd_remap(blockIdx.x, ntiles) * BM + wave * 32;
+  const int row = min(m0 + l, M - 1);
+  const int nchunk = HID / HC;
+
+  for (int i = tid; i < HID / 4; i += 256) ((f32x4*)b1s)[i] = ((const f32x4*)b1)[i];
+
+  // X fragments of the wave's 32 rows (B operand of phase A): 16 k-steps
+  f16x8 xf[C / 16];
+  const f16* xp = X + (int64_t)row * ldx + 8 * hh;
+#pragma unroll
+  for (int s = 0; s < C / 16; ++s) xf[s] = *(const f16x8*)(xp + 16 * s);
+  // Y^T accumulators = src + b2 : lane (m = l, hh), tile nt, reg r <-> column 32 nt + 8 (r >> 2) + 4 hh + (r & 3)
+  f32x16 y[C / 32];
+  const float* rp = res + (int64_t)row * C + 4 * hh;
+#pragma unroll
+  for (int nt = 0; nt < C / 32; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 r4 = *(const f32x4*)(rp + 32 * nt + 8 * g);
+      const f32x4 c4 = *(const f32x4*)(b2 + 32 * nt + 8 * g + 4 * hh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[nt][4 * g + e] = r4[e] + c4[e];
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on only the LDS-DMA is in flight
+
+  auto stage = [&](int buf, int c) {
+    const char* src = (const char*)blob + (int64_t)c * CHUNK + lane * 16;
+    char* dst = smem + buf * CHUNK;
+#pragma unroll
+    for (int i = 0; i < (W1_BLKS + W2_BLKS) / 4; ++i) {
+      const int q = wave * ((W1_BLKS + W2_BLKS) / 4) + i;
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + q * BLK), (lptr_t)(dst + q * BLK), 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+
+  for (int c = 0; c < nchunk; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of chunk c has landed
+    __builtin_amdgcn_s_barrier();                        // everyone's has; everyone is done reading chunk c - 1
+    asm volatile("" ::: "memory");
+    if (c + 1 < nchunk) stage((c + 1) & 1, c + 1);
+    const char* w1 = smem + (c & 1) * CHUNK + lane * 16;
+    const char* w2 = w1 + W1_BLKS * BLK;
+
+    // ---- phase A: H^T chunk = W1c X^T + b1
+    f32x16 h[HC / 32];
+#pragma unroll
+    for (int jt = 0; jt < HC / 32; ++jt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *(const f32x4*)(b1s + c * HC + 32 * jt + 8 * g + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[jt][4 * g + e] = b4[e];
+      }
+#pragma unroll
+    for (int s = 0; s < C / 16; ++s)
+#pragma unroll
+      for (int jt = 0; jt < HC / 32; ++jt)
+        h[jt] = mfma32(*(const f16x8*)(w1 + (jt * (C / 16) + s) * BLK), xf[s], h[jt]);
+
+    // ---- relu + f16: registers 8 (s & 1) .. + 7 of tile s >> 1 are the lane's B-operand of k-step s (hid_perm)
+    f16x8 hf[HC / 16];
+#pragma unroll
+    for (int s = 0; s < HC / 16; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hf[s][e] = (f16)fmaxf(h[s >> 1][8 * (s & 1) + e], 0.0f);
+
+    // ---- phase B: Y^T += W2c H^T
+#pragma unroll
+    for (int s = 0; s < HC / 16; ++s)
+#pragma unroll
+      for (int nt = 0; nt < C / 32; ++nt)
+        y[nt] = mfma32(*(const f16x8*)(w2 + (nt * (HC / 16) + s) * BLK), hf[s], y[nt]);
+  }
+
+  // ---- LayerNorm over the 256 columns of the lane's row: 128 values here, 128 in lane ^ 32
+  float sum = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < C / 32; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += y[nt][r];
+  sum += __shfl_xor(sum, 32, 64);
+  const float mean = sum * (1.0f / C);
+  float sq = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < C / 32; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = y[nt][r] - mean;
+      sq += d * d;
+    }
+  sq += __shfl_xor(sq, 32, 64);
+  const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + eps);
+
+  __syncthreads();                                       // all waves are done with the weight buffers
+  char* ot = smem + wave * 32 * OROW;                    // wave-private tile: 32 rows of 256 f32
+#pragma unroll
+  for (int nt = 0; nt < C / 32; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = 32 * nt + 8 * g + 4 * hh;
+      const f32x4 gm = *(const f32x4*)(ln_g + col), bt = *(const f32x4*)(ln_b + col);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (y[nt][4 * g + e] - mean) * rstd * gm[e] + bt[e];
+      *(f32x4*)(ot + l * OROW + col * 4) = v;
+    }
+  // (wave-private tile: the wave's own LDS writes are ordered before its reads by the lgkmcnt wait)
+  // rows leave as 1-KiB segments: one row per instruction (64 lanes x 16 B)
+#pragma unroll 4
+  for (int r = 0; r < 32; ++r) {
+    const int m = m0 + r;
+    if (m < M) *(f32x4*)(out + (int64_t)m * C + lane * 4) = *(const f32x4*)(ot + r * OROW + lane * 16);
+  }
+}
+
+}  // namespace
+
+extern "C" int ink_ffn256_pack_bytes(int32_t hid, int64_t* out_bytes) {
+  INK_CHECK_ARG(out_bytes && hid > 0 && hid % HC == 0 && hid <= MAX_HID);
+  *out_bytes = (int64_t)(hid / HC) * CHUNK;
+  return INK_OK;
+}
+
+extern "C" int ink_ffn256_pack(const void* w1_f16, const void* w2_f16, int32_t hid, void* blob, void* stream) {
+  INK_CHECK_ARG(w1_f16 && w2_f16 && blob && hid > 0 && hid % HC == 0 && hid <= MAX_HID);
+  INK_CHECK_ARG((((uintptr_t)w1_f16 | (uintptr_t)blob) & 15) == 0);
+  const int64_t pieces = (int64_t)(hid / HC) * (W1_BLKS + W2_BLKS) * 64;
+  hipLaunchKernelGGL(ffn256_pack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f16*)w1_f16, (const f16*)w2_f16, hid, (f16*)blob);
+  return ink_launch_status();
+}
+
+extern "C" int ink_ffn256_fused(const void* x_f16, int64_t ldx, const float* res_f32, const void* blob, const float* b1,
+                                const float* b2, const float* ln_g, const float* ln_b, float eps, int32_t M, int32_t hid,
+                                float* out_f32, void* stream) {
+  INK_CHECK_ARG(x_f16 && res_f32 && blob && b1 && b2 && ln_g && ln_b && out_f32);
+  INK_CHECK_ARG(M > 0 && hid > 0 && hid % HC == 0 && hid <= MAX_HID && ldx >= C && ldx % 8 == 0);
+  INK_CHECK_ARG((((uintptr_t)x_f16 | (uintptr_t)res_f32 | (uintptr_t)blob | (uintptr_t)b1 | (uintptr_t)b2 |
+                  (uintptr_t)ln_g | (uintptr_t)ln_b | (uintptr_t)out_f32) & 15) == 0);
+  static bool attr = ((void)hipFuncSetAttribute((const void*)ffn256_fused_kernel,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), true);
+  (void)attr;
+  const int ntiles = (M + BM - 1) / BM;
+  hipLaunchKernelGGL(ffn256_fused_kernel, dim3(ntiles), dim3(256), LDS_BYTES, (hipStream_t)stream, (const f16*)x_f16, ldx,
+                     res_f32, (const f16*)blob, b1, b2, ln_g, ln_b, eps, M, hid, out_f32);
+  return ink_launch_status();
+}
