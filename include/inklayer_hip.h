@@ -331,6 +331,20 @@ int ink_fusion_fold(float* v_f32, int32_t B, int32_t S, const float* lnv_g, cons
                     const float* bq, const void* Wvv_f16, const float* bvv, const void* Wo_f16, const float* bo,
                     const float* gamma_v, float scale, float* ws, void* out_l_f16, void* stream);
 
+/* Feed-forward block of the deformable encoder layer, fused (csrc/ffn_fused.hip):
+ *     out = LayerNorm(res + linear2(relu(linear1(x))))      d_model 256, d_ffn = hid (multiple of 64, <= 2048)
+ * = DeformableTransformerEncoderLayer.forward_ffn + norm2 (GD/models/GroundingDINO/transformer.py:780-799).  x f16 [M, 256]
+ * (row stride ldx) is the GEMM operand (f16 of the layer's input), res f32 [M, 256] the same rows in f32 (the residual);
+ * out f32 [M, 256] may alias res.  The hidden activations are rounded to f16 between the two products, as in the two-GEMM
+ * form.  blob: the weights packed by ink_ffn256_pack (ink_ffn256_pack_bytes(hid) bytes, 16-B aligned) from linear1.weight
+ * f16 [hid, 256], linear1.bias f32 [hid] (carried as an f16 hi + lo pair in a 17th k-step, i.e. to 2^-22) and
+ * linear2.weight f16 [256, hid]: per 64 hidden units the LDS image the kernel streams - 1-KiB MFMA operand blocks,
+ * linear2's columns permuted inside 16-blocks to the order phase A leaves them in registers.  b2: linear2.bias. */
+int ink_ffn256_pack_bytes(int32_t hid, int64_t* out_bytes);
+int ink_ffn256_pack(const void* w1_f16, const float* b1, const void* w2_f16, int32_t hid, void* blob, void* stream);
+int ink_ffn256_fused(const void* x_f16, int64_t ldx, const float* res_f32, const void* blob, const float* b2,
+                     const float* ln_g, const float* ln_b, float eps, int32_t M, int32_t hid, float* out_f32, void* stream);
+
 /* Two-stage query selection (transformer.py:293-300): indices of the K largest max_t logits[b,s,t],
  * descending, ties -> lower index.  logits f32 [B,S,T]; out_idx int32 [B,K].  S <= 16384 is one LDS
  * bitonic sort per image; larger S (800x1333 inputs give 22223 tokens) sorts ceil(S/16384) equal chunks and

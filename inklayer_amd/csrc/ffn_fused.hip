@@ -21,6 +21,7 @@
 //   * Epilogue: a lane holds half of its row (128 values), the other half sits in lane ^ 32: LayerNorm statistics are
 //     in-lane sums + one cross-half exchange; rows leave through LDS (the weight buffers are free by then) as whole
 //     1-KiB rows.
+#include <type_traits>
 #include "common.h"
 #include "../../include/inklayer_hip.h"
 
@@ -31,13 +32,44 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int C = 256, HC = 64, BM = 128;
 constexpr int BLK = 1024;                       // one A-operand block: 32 rows x 16 k of f16, lane-linear
-constexpr int W1_BLKS = (HC / 32) * (C / 16);   // 32: (jt, s)
+constexpr int KA = C / 16 + 1;                  // k-steps of phase A: 16 of x . W1 + one that carries b1 (x' = [x | 1 1 0 ..])
+constexpr int W1_BLKS = (HC / 32) * KA;         // 34: (jt, s)
 constexpr int W2_BLKS = (C / 32) * (HC / 16);   // 32: (nt, s)
-constexpr int CHUNK = (W1_BLKS + W2_BLKS) * BLK;   // 64 KiB per chunk of 64 hidden units
+constexpr int NBLK = W1_BLKS + W2_BLKS;         // 66 blocks = MFMAs = fragment reads per chunk and wave
+constexpr int CHUNK = NBLK * BLK;               // 66 KiB per chunk of 64 hidden units
 constexpr int MAX_HID = 2048;
 constexpr int OROW = C * 4 + 16;                // epilogue staging row (f32) + pad
-constexpr int LDS_BYTES = 2 * CHUNK + MAX_HID * 4;
-static_assert(4 * 32 * OROW <= 2 * CHUNK, "epilogue staging fits the weight buffers");
+constexpr int LDS_BYTES = 2 * CHUNK;
+#ifndef INK_FFN_DEPTH
+#define INK_FFN_DEPTH 6
+#endif
+constexpr int DEPTH = INK_FFN_DEPTH;            // fragment reads in flight ahead of the MFMA that consumes them
+constexpr int NSLOT = (NBLK + 3) / 4;           // LDS-DMA pieces per wave and chunk (17; piece index clamped to NBLK - 1)
+static_assert(4 * 32 * OROW <= LDS_BYTES, "epilogue staging fits the (then free) weight buffers");
+
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+template <int I> using ic = std::integral_constant<int, I>;
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(ic<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// Fragment reads are volatile asm so that they KEEP their distance to the MFMA that consumes them (left to itself hipcc
+// sinks every ds_read next to its use and waits lgkmcnt(0) in front of each MFMA: 6000 instead of 2100 cycles per chunk);
+// the counted wait is tied to the fragment it releases, which orders the MFMA behind it.  Nothing else in the loop uses
+// lgkmcnt, and LDS returns in order.
+template <int OFF>
+__device__ __forceinline__ f16x8 lds_frag(uint32_t addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_frag(f16x8& f) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N));
+}
 
 __device__ __forceinline__ f32x16 mfma32(const f16x8& a, const f16x8& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -46,19 +78,26 @@ __device__ __forceinline__ f32x16 mfma32(const f16x8& a, const f16x8& b, const f
 // position p = 8 hh + e of a 16-wide k-step of phase B  <->  hidden unit (within the 16-block) the lane holds there
 __host__ __device__ constexpr int hid_perm(int p) { return (p & 7) < 4 ? 4 * (p >> 3) + (p & 7) : 8 + 4 * (p >> 3) + (p & 7) - 4; }
 
-__global__ __launch_bounds__(256) void ffn256_pack_kernel(const f16* __restrict__ W1, const f16* __restrict__ W2, int HID,
-                                                          f16* __restrict__ blob) {
+__global__ __launch_bounds__(256) void ffn256_pack_kernel(const f16* __restrict__ W1, const float* __restrict__ b1,
+                                                          const f16* __restrict__ W2, int HID, f16* __restrict__ blob) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one 16-B piece of the blob
-  const int64_t total = (int64_t)(HID / HC) * (W1_BLKS + W2_BLKS) * 64;
+  const int64_t total = (int64_t)(HID / HC) * NBLK * 64;
   if (idx >= total) return;
   const int lane = (int)(idx & 63);
-  const int q = (int)((idx >> 6) % (W1_BLKS + W2_BLKS));
-  const int c = (int)((idx >> 6) / (W1_BLKS + W2_BLKS));
+  const int q = (int)((idx >> 6) % NBLK);
+  const int c = (int)((idx >> 6) / NBLK);
   const int l = lane & 31, hh = lane >> 5;
-  f16x8 v;
+  f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
   if (q < W1_BLKS) {
-    const int jt = q / (C / 16), s = q % (C / 16);
-    v = *(const f16x8*)(W1 + (int64_t)(c * HC + 32 * jt + l) * C + 16 * s + 8 * hh);
+    const int jt = q / KA, s = q % KA;
+    const int j = c * HC + 32 * jt + l;
+    if (s < C / 16) {
+      v = *(const f16x8*)(W1 + (int64_t)j * C + 16 * s + 8 * hh);
+    } else if (hh == 0) {              // the bias k-step: b1 as hi + lo against x' = (1, 1, 0, ...)
+      const f16 hi = (f16)b1[j];
+      v[0] = hi;
+      v[1] = (f16)(b1[j] - (float)hi);
+    }
   } else {
     const int nt = (q - W1_BLKS) / (HC / 16), s = (q - W1_BLKS) % (HC / 16);
     const f16* src = W2 + (int64_t)(32 * nt + l) * HID + c * HC + 16 * s;
@@ -70,25 +109,25 @@ __global__ __launch_bounds__(256) void ffn256_pack_kernel(const f16* __restrict_
 
 __global__ __launch_bounds__(256) void ffn256_fused_kernel(const f16* __restrict__ X, int64_t ldx,
                                                            const float* __restrict__ res, const f16* __restrict__ blob,
-                                                           const float* __restrict__ b1, const float* __restrict__ b2,
-                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                                           float eps, int M, int HID, float* __restrict__ out) {
+                                                           const float* __restrict__ b2, const float* __restrict__ ln_g,
+                                                           const float* __restrict__ ln_b, float eps, int M, int HID,
+                                                           float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* b1s = (float*)(smem + 2 * CHUNK);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the LDS-DMA's M0 and base address are SALU work
   const int l = lane & 31, hh = lane >> 5;
   const int ntiles = (M + BM - 1) / BM;
   const int m0 = xcd_remap(blockIdx.x, ntiles) * BM + wave * 32;
   const int row = min(m0 + l, M - 1);
   const int nchunk = HID / HC;
 
-  for (int i = tid; i < HID / 4; i += 256) ((f32x4*)b1s)[i] = ((const f32x4*)b1)[i];
-
-  // X fragments of the wave's 32 rows (B operand of phase A): 16 k-steps
-  f16x8 xf[C / 16];
+  // X' fragments of the wave's 32 rows (B operand of phase A): 16 k-steps of x + the bias step (1, 1, 0, ...)
+  f16x8 xf[KA];
   const f16* xp = X + (int64_t)row * ldx + 8 * hh;
 #pragma unroll
   for (int s = 0; s < C / 16; ++s) xf[s] = *(const f16x8*)(xp + 16 * s);
+  xf[C / 16] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  if (hh == 0) xf[C / 16][0] = xf[C / 16][1] = (f16)1.0f;
   // Y^T accumulators = src + b2 : lane (m = l, hh), tile nt, reg r <-> column 32 nt + 8 (r >> 2) + 4 hh + (r & 3)
   f32x16 y[C / 32];
   const float* rp = res + (int64_t)row * C + 4 * hh;
@@ -103,54 +142,63 @@ __global__ __launch_bounds__(256) void ffn256_fused_kernel(const f16* __restrict
     }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on only the LDS-DMA is in flight
 
-  auto stage = [&](int buf, int c) {
-    const char* src = (const char*)blob + (int64_t)c * CHUNK + lane * 16;
-    char* dst = smem + buf * CHUNK;
-#pragma unroll
-    for (int i = 0; i < (W1_BLKS + W2_BLKS) / 4; ++i) {
-      const int q = wave * ((W1_BLKS + W2_BLKS) / 4) + i;
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + q * BLK), (lptr_t)(dst + q * BLK), 16, 0, 0);
-    }
+  // LDS-DMA piece k of this wave for chunk c: block min(4 k + wave, NBLK - 1) (the two waves without a 17th piece
+  // re-copy the last block: same bytes).  One piece per four MFMAs of the previous chunk: a piece costs ~60 cycles of
+  // issue, which one wave per SIMD cannot hide behind more than the MFMAs already in flight.
+  auto stage = [&](int buf, int c, int k) {
+    const int q = min(4 * k + wave, NBLK - 1);
+    __builtin_amdgcn_global_load_lds((gptr_t)((const char*)blob + (int64_t)c * CHUNK + q * BLK + lane * 16),
+                                     (lptr_t)(smem + buf * CHUNK + q * BLK), 16, 0, 0);
   };
-  stage(0, 0);
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) stage(0, 0, k);
 
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_ptr)smem + lane * 16;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int c = 0; c < nchunk; ++c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of chunk c has landed
     __builtin_amdgcn_s_barrier();                        // everyone's has; everyone is done reading chunk c - 1
     asm volatile("" ::: "memory");
-    if (c + 1 < nchunk) stage((c + 1) & 1, c + 1);
-    const char* w1 = smem + (c & 1) * CHUNK + lane * 16;
-    const char* w2 = w1 + W1_BLKS * BLK;
+    const int cn = min(c + 1, nchunk - 1);               // the last chunk re-stages itself into the idle buffer: no branch
+    const uint32_t wa = lds0 + (c & 1) * CHUNK;          // phase-A blocks; phase-B blocks follow at + W1_BLKS * BLK
+    const uint32_t wb = wa + W1_BLKS * BLK;
 
-    // ---- phase A: H^T chunk = W1c X^T + b1
+    // step i < 34: phase A, k-step i / 2 of hidden tile i % 2;  i >= 34: phase B, k-step (i - 34) / 8 of column tile % 8
+    f16x8 fr[DEPTH + 1];
+    auto read = [&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      if constexpr (i < W1_BLKS) fr[i % (DEPTH + 1)] = lds_frag<((i % 2) * KA + i / 2) * BLK>(wa);
+      else fr[i % (DEPTH + 1)] = lds_frag<(((i - W1_BLKS) % 8) * (HC / 16) + (i - W1_BLKS) / 8) * BLK>(wb);
+    };
+    static_for<0, DEPTH>(read);
     f32x16 h[HC / 32];
-#pragma unroll
-    for (int jt = 0; jt < HC / 32; ++jt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 b4 = *(const f32x4*)(b1s + c * HC + 32 * jt + 8 * g + 4 * hh);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[jt][4 * g + e] = b4[e];
-      }
-#pragma unroll
-    for (int s = 0; s < C / 16; ++s)
-#pragma unroll
-      for (int jt = 0; jt < HC / 32; ++jt)
-        h[jt] = mfma32(*(const f16x8*)(w1 + (jt * (C / 16) + s) * BLK), xf[s], h[jt]);
-
-    // ---- relu + f16: registers 8 (s & 1) .. + 7 of tile s >> 1 are the lane's B-operand of k-step s (hid_perm)
     f16x8 hf[HC / 16];
+    static_for<0, NBLK>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+#ifndef INK_FFN_NOREAD
+      if constexpr (i + DEPTH < NBLK) read(ic<i + DEPTH>{});
+#endif
+#ifndef INK_FFN_NOREAD
+      wait_frag<(NBLK - 1 - i < DEPTH ? NBLK - 1 - i : DEPTH)>(fr[i % (DEPTH + 1)]);
+#else
+      wait_frag<0>(fr[i % (DEPTH + 1)]);
+#endif
+      if constexpr (i < W1_BLKS) {
+        constexpr int s = i / 2, jt = i % 2;
+        h[jt] = mfma32(fr[i % (DEPTH + 1)], xf[s], s == 0 ? zero : h[jt]);
+      } else {
+        constexpr int s = (i - W1_BLKS) / 8, nt = (i - W1_BLKS) % 8;
+        if constexpr (nt == 0) {
+          // relu + f16: registers 8 (s & 1) .. + 7 of hidden tile s >> 1 are the lane's B operand of k-step s (hid_perm)
 #pragma unroll
-    for (int s = 0; s < HC / 16; ++s)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) hf[s][e] = (f16)fmaxf(h[s >> 1][8 * (s & 1) + e], 0.0f);
-
-    // ---- phase B: Y^T += W2c H^T
-#pragma unroll
-    for (int s = 0; s < HC / 16; ++s)
-#pragma unroll
-      for (int nt = 0; nt < C / 32; ++nt)
-        y[nt] = mfma32(*(const f16x8*)(w2 + (nt * (HC / 16) + s) * BLK), hf[s], y[nt]);
+          for (int e = 0; e < 8; ++e) hf[s][e] = (f16)fmaxf(h[s >> 1][8 * (s & 1) + e], 0.0f);
+        }
+        y[nt] = mfma32(fr[i % (DEPTH + 1)], hf[s], y[nt]);
+      }
+#ifndef INK_FFN_NODMA          // (timing experiments of tools/ffn_variants.sh: wrong results)
+      if constexpr (i % 4 == 1) stage((c + 1) & 1, cn, i / 4);
+#endif
+    });
   }
 
   // ---- LayerNorm over the 256 columns of the lane's row: 128 values here, 128 in lane ^ 32
@@ -172,6 +220,7 @@ __global__ __launch_bounds__(256) void ffn256_fused_kernel(const f16* __restrict
   sq += __shfl_xor(sq, 32, 64);
   const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + eps);
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the idle re-stage of the last chunk
   __syncthreads();                                       // all waves are done with the weight buffers
   char* ot = smem + wave * 32 * OROW;                    // wave-private tile: 32 rows of 256 f32
 #pragma unroll
@@ -202,27 +251,28 @@ extern "C" int ink_ffn256_pack_bytes(int32_t hid, int64_t* out_bytes) {
   return INK_OK;
 }
 
-extern "C" int ink_ffn256_pack(const void* w1_f16, const void* w2_f16, int32_t hid, void* blob, void* stream) {
-  INK_CHECK_ARG(w1_f16 && w2_f16 && blob && hid > 0 && hid % HC == 0 && hid <= MAX_HID);
+extern "C" int ink_ffn256_pack(const void* w1_f16, const float* b1, const void* w2_f16, int32_t hid, void* blob,
+                               void* stream) {
+  INK_CHECK_ARG(w1_f16 && b1 && w2_f16 && blob && hid > 0 && hid % HC == 0 && hid <= MAX_HID);
   INK_CHECK_ARG((((uintptr_t)w1_f16 | (uintptr_t)blob) & 15) == 0);
-  const int64_t pieces = (int64_t)(hid / HC) * (W1_BLKS + W2_BLKS) * 64;
+  const int64_t pieces = (int64_t)(hid / HC) * NBLK * 64;
   hipLaunchKernelGGL(ffn256_pack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const f16*)w1_f16, (const f16*)w2_f16, hid, (f16*)blob);
+                     (const f16*)w1_f16, b1, (const f16*)w2_f16, hid, (f16*)blob);
   return ink_launch_status();
 }
 
-extern "C" int ink_ffn256_fused(const void* x_f16, int64_t ldx, const float* res_f32, const void* blob, const float* b1,
-                                const float* b2, const float* ln_g, const float* ln_b, float eps, int32_t M, int32_t hid,
-                                float* out_f32, void* stream) {
-  INK_CHECK_ARG(x_f16 && res_f32 && blob && b1 && b2 && ln_g && ln_b && out_f32);
+extern "C" int ink_ffn256_fused(const void* x_f16, int64_t ldx, const float* res_f32, const void* blob, const float* b2,
+                                const float* ln_g, const float* ln_b, float eps, int32_t M, int32_t hid, float* out_f32,
+                                void* stream) {
+  INK_CHECK_ARG(x_f16 && res_f32 && blob && b2 && ln_g && ln_b && out_f32);
   INK_CHECK_ARG(M > 0 && hid > 0 && hid % HC == 0 && hid <= MAX_HID && ldx >= C && ldx % 8 == 0);
-  INK_CHECK_ARG((((uintptr_t)x_f16 | (uintptr_t)res_f32 | (uintptr_t)blob | (uintptr_t)b1 | (uintptr_t)b2 |
+  INK_CHECK_ARG((((uintptr_t)x_f16 | (uintptr_t)res_f32 | (uintptr_t)blob | (uintptr_t)b2 |
                   (uintptr_t)ln_g | (uintptr_t)ln_b | (uintptr_t)out_f32) & 15) == 0);
   static bool attr = ((void)hipFuncSetAttribute((const void*)ffn256_fused_kernel,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), true);
   (void)attr;
   const int ntiles = (M + BM - 1) / BM;
   hipLaunchKernelGGL(ffn256_fused_kernel, dim3(ntiles), dim3(256), LDS_BYTES, (hipStream_t)stream, (const f16*)x_f16, ldx,
-                     res_f32, (const f16*)blob, b1, b2, ln_g, ln_b, eps, M, hid, out_f32);
+                     res_f32, (const f16*)blob, b2, ln_g, ln_b, eps, M, hid, out_f32);
   return ink_launch_status();
 }

@@ -214,6 +214,7 @@ def clean_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 
 class GDinoEngine:
+    fuse_ffn = True          # encoder FFN + norm2 as one kernel (csrc/ffn_fused.hip); False: two GEMMs + LayerNorm
     fold_fusion = True       # the caption's tokens folded through the fusion layers (csrc/fusion_fold.hip); False: rounds 1-2 path
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[GDinoConfig] = None,
@@ -307,6 +308,8 @@ class GDinoEngine:
             p, d = f"{t}encoder.layers.{i}.", f"e{i}"
             msda(d + ".msda", p + "self_attn.")
             ln(d + ".norm1", p + "norm1"); lin(d + ".lin1", p + "linear1"); lin(d + ".lin2", p + "linear2"); ln(d + ".norm2", p + "norm2")
+            if w[d + ".lin1.w"].shape[1] == 256 and w[d + ".lin1.w"].shape[0] % 64 == 0 and w[d + ".lin1.w"].shape[0] <= 2048:
+                w[d + ".ffn.blob"] = ops.ffn256_pack(w[d + ".lin1.w"], w[d + ".lin1.b"], w[d + ".lin2.w"])     # csrc/ffn_fused.hip
             p = f"{t}encoder.text_layers.{i}."
             mha(d + ".txt", p + "self_attn.")
             lin(d + ".txt.lin1", p + "linear1"); lin(d + ".txt.lin2", p + "linear2")
@@ -514,9 +517,14 @@ class GDinoEngine:
             o = ops.msda_fused(val, proj, pl.enc_ref, pl.shapes, B, S, ref_batched=False)
             y = ops.gemm(o, w[d + ".msda.out.w"], w[d + ".msda.out.b"], residual=src, out=src)
             ops.layernorm_rows(y, w[d + ".norm1.w"], w[d + ".norm1.b"], 1e-5, out=src, out2=s16)
-            ff = ops.gemm(s16, w[d + ".lin1.w"], w[d + ".lin1.b"], act="relu", out_dtype=F16)
-            y = ops.gemm(ff, w[d + ".lin2.w"], w[d + ".lin2.b"], residual=src, out=src)
-            ops.layernorm_rows(y, w[d + ".norm2.w"], w[d + ".norm2.b"], 1e-5, out=src)
+            if self.fuse_ffn and (d + ".ffn.blob") in w:
+                # linear1 + relu + linear2 + residual + norm2 in one kernel: the [B*S, 2048] hidden tensor stays in registers
+                ops.ffn256_fused(s16, src, w[d + ".ffn.blob"], int(w[d + ".lin1.b"].numel()), w[d + ".lin2.b"],
+                                 w[d + ".norm2.w"], w[d + ".norm2.b"], 1e-5, out=src)
+            else:
+                ff = ops.gemm(s16, w[d + ".lin1.w"], w[d + ".lin1.b"], act="relu", out_dtype=F16)
+                y = ops.gemm(ff, w[d + ".lin2.w"], w[d + ".lin2.b"], residual=src, out=src)
+                ops.layernorm_rows(y, w[d + ".norm2.w"], w[d + ".norm2.b"], 1e-5, out=src)
         return src, text
 
     def decoder(self, memory: torch.Tensor, text: torch.Tensor, pl: _Plan, B: int, stages: Optional[dict] = None):

@@ -570,6 +570,42 @@ def fusion_fold(v: torch.Tensor, B: int, S: int, lnv_g: torch.Tensor, lnv_b: tor
     return out_l
 
 
+def ffn256_pack(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """linear1.weight f16 [hid, 256] + linear1.bias f32 [hid] + linear2.weight f16 [256, hid] -> the packed weight blob of
+    ffn256_fused (done once at load time; csrc/ffn_fused.hip)."""
+    hid = int(w1.shape[0])
+    assert w1.dtype == F16 and w2.dtype == F16 and w1.is_contiguous() and w2.is_contiguous()
+    assert tuple(w1.shape) == (hid, 256) and tuple(w2.shape) == (256, hid)
+    assert b1.dtype == F32 and b1.is_contiguous() and b1.numel() == hid
+    need = C.c_int64(0)
+    check(_lib.lib().ink_ffn256_pack_bytes(hid, C.byref(need)), "ink_ffn256_pack_bytes")
+    blob = torch.empty(need.value // 2, device=w1.device, dtype=F16)
+    check(_lib.lib().ink_ffn256_pack(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), hid, blob.data_ptr(), _stream()),
+          "ink_ffn256_pack")
+    return blob
+
+
+def ffn256_fused(x16: torch.Tensor, res: torch.Tensor, blob: torch.Tensor, hid: int, b2: torch.Tensor,
+                 ln_g: torch.Tensor, ln_b: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm(res + linear2(relu(linear1(x16)))) for d_model 256 in one kernel (transformer.py:780-799).  x16 f16
+    [M, 256] (row stride free), res f32 [M, 256]; blob = ffn256_pack(...) of a d_ffn = hid layer; out f32 [M, 256] (may be
+    `res`)."""
+    M = int(x16.shape[0])
+    assert x16.dtype == F16 and x16.stride(1) == 1 and x16.shape[1] == 256
+    assert res.dtype == F32 and res.is_contiguous() and tuple(res.shape) == (M, 256)
+    need = C.c_int64(0)
+    check(_lib.lib().ink_ffn256_pack_bytes(hid, C.byref(need)), "ink_ffn256_pack_bytes")
+    assert blob.dtype == F16 and blob.numel() * 2 == need.value and b2.dtype == F32
+    assert b2.numel() == 256 and ln_g.numel() == 256 and ln_b.numel() == 256 and ln_g.dtype == F32 and ln_b.dtype == F32
+    if out is None:
+        out = torch.empty_like(res)
+    assert out.dtype == F32 and out.is_contiguous() and tuple(out.shape) == (M, 256)
+    check(_lib.lib().ink_ffn256_fused(x16.data_ptr(), x16.stride(0), res.data_ptr(), blob.data_ptr(), b2.data_ptr(),
+                                      ln_g.data_ptr(), ln_b.data_ptr(), eps, M, hid, out.data_ptr(), _stream()),
+          "ink_ffn256_fused")
+    return out
+
+
 def attn_fewkeys(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, B: int, n_heads: int, head_dim: int,
                  scale: float, blocked: Optional[torch.Tensor] = None, n_q: Optional[int] = None,
                  q_batch_rows: Optional[torch.Tensor] = None, q_add: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -418,3 +418,39 @@ def test_gemm_split_stream_and_layernorm_fold(dev, M):
     wp = want.view(M, D // chunk, chunk)
     assert (st2[..., 0].double() - wp.sum(-1)).abs().max().item() < 2e-3
     assert ((st2[..., 1].double() - (wp ** 2).sum(-1)).abs() / (wp ** 2).sum(-1)).max().item() < 2e-5
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("M,hid", [(1000, 2048), (128, 2048), (37, 128), (13294 + 5, 1024)])
+def test_fused_ffn_equals_the_two_projection_form(dev, M, hid):
+    """ink_ffn256_fused = LayerNorm(res + linear2(relu(linear1(x)))) (transformer.py:780-799) against float64 with the
+    same two rounding points as the two-GEMM form (f16 operand x, f16 hidden activations) and against that form itself
+    (ops.gemm x 2 + layernorm_rows).  Ragged M: the last workgroup's rows are clamped / masked."""
+    from inklayer_amd import ops
+    g = torch.Generator().manual_seed(M + hid)
+    x32 = torch.randn(M, 256, generator=g) * 1.5 + 0.3
+    w1 = (torch.randn(hid, 256, generator=g) / 16).half()
+    w2 = (torch.randn(256, hid, generator=g) / 45).half()
+    b1, b2 = torch.randn(hid, generator=g) * 0.2, torch.randn(256, generator=g) * 0.2
+    lg, lb = 1 + 0.1 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g)
+    x16 = x32.half()
+    h = torch.relu(x16.double() @ w1.double().T + b1.double()).float().half()
+    y = x32.double() + h.double() @ w2.double().T + b2.double()
+    want = torch.nn.functional.layer_norm(y, (256,), lg.double(), lb.double(), 1e-5)
+    d = lambda t: t.to(dev).contiguous()
+    blob = ops.ffn256_pack(d(w1), d(b1), d(w2))
+    xs = d(x32)
+    got = ops.ffn256_fused(d(x16), xs, blob, hid, d(b2), d(lg), d(lb), 1e-5)
+    ea = (got.double().cpu() - want).abs()
+    err, mean_err = ea.max().item(), ea.mean().item()
+    print(f"M={M} hid={hid}: fused FFN vs float64 max abs {err:.2e}, mean abs {mean_err:.2e}")
+    # the f16 rounding of a hidden activation near a tie can go the other way than in float64 (f32 accumulation): one
+    # f16 ulp of one hidden unit moves its row by up to ~3e-4; everything else is f32 accumulation noise
+    assert torch.isfinite(got).all() and err < 1e-3 and mean_err < 5e-6
+    ff = ops.gemm(d(x16), d(w1), d(b1), act="relu", out_dtype=torch.float16)
+    y2 = ops.gemm(ff, d(w2), d(b2), residual=xs.clone())
+    two = ops.layernorm_rows(y2, d(lg), d(lb), 1e-5, out_dtype=torch.float32)
+    assert (got - two).abs().max().item() < 1e-3 and (got - two).abs().mean().item() < 5e-6
+    # in place: out aliases res
+    got2 = ops.ffn256_fused(d(x16), xs, blob, hid, d(b2), d(lg), d(lb), 1e-5, out=xs)
+    assert got2.data_ptr() == xs.data_ptr() and torch.equal(got2, got)
