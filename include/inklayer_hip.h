@@ -90,8 +90,8 @@ int ink_gemm_query_stats_chunk(int32_t M, int32_t N, int32_t K);
  * (GD/.../swin_transformer.py:246-265).  x is f32; out is f16 and/or f32.
  * C % 4 == 0, C <= 2048.  act: INK_ACT_NONE or INK_ACT_GELU applied after the affine
  * (LayerNorm2d + GELU of SA/modeling/mask_decoder.py:54-56).
- * split = 1: out_f16 rows are SPLIT-f16 operands [hi | lo*64 | hi/64] of 3*C columns (ldo >= 3*C, out_f32 NULL),
- * see ink_add_split_f16.
+ * split = 1: out_f16 rows are SPLIT-f16 operands [hi | lo*64 | hi/64] of 3*C columns (ldo >= 3*C), see
+ * ink_add_split_f16; an f32 copy may be written in the same pass: out_f32 rows then have stride ldo / 3.
  * add (f32 or NULL, not together with gather): the row normalised is x[r] + add[add_batch_rows[r / rows_per_batch] +
  * r % rows_per_batch] (add_batch_rows NULL: add[r]) - the residual add of SA/modeling/transformer.py:180-181 when the
  * image keys are still shared by all boxes of an image (no per-box copy of them is ever made).

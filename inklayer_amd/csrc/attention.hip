@@ -640,9 +640,11 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
                                   (((uintptr_t)p.pad_k | (uintptr_t)p.pad_v) & 15) == 0));
     // SAM's own window size (14 x 14 = 196 keys): the one-wave-per-SIMD kernel of attention_win.hip.  Its output
     // stores go through a 2 GiB buffer descriptor (invalid rows are dropped by the bounds check).
+#ifndef INK_EXP_NO_WIN4        // (experiment: the round-1 window kernel instead, tools/race_variants.sh)
     if (p.n_k >= 193 && p.n_k <= 208 && p.n_q <= 256 &&
         (p.tok_rows || (int64_t)p.n_batch * p.n_q * p.ldo * 2 < 0x80000000LL))
       return ink_win4_attn_launch(p, n_cus, s);
+#endif
     INK_FA_X(80, 2, 7, true);
   } else if (p.head_dim == 80 && p.bias_mode == 0) {
     INK_FA(80, 0, 4);

@@ -87,8 +87,14 @@ constexpr int HD = 80, NT = 256, NQKB = 5, NQK = 7, NB = 3, CH = 10;
 constexpr int KROW = 240, VROW = 192, ROWS = 232;     // K' rows: k | one-hot(kh, kw) | pad; V rows: v | ones-column | pad
 constexpr int SKEYS = 25, SIT = 9, STHR = SKEYS * CH;
 constexpr int XROW = 176;                             // wave-private staging tile: 64 O rows of 160 B
-constexpr int LDS_BYTES = ROWS * KROW + ROWS * VROW + 256 * 4 + 4 * 64 * XROW + 4 * 64 * 4;
+#ifndef INK_EXP_LDS_SLACK
+#define INK_EXP_LDS_SLACK 0          // (experiment, tools/race_variants.sh: unused bytes requested after the kernel's own)
+#endif
+constexpr int LDS_BYTES = ROWS * KROW + ROWS * VROW + 256 * 4 + 4 * 64 * XROW + 4 * 64 * 4 + INK_EXP_LDS_SLACK;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+#ifndef INK_WIN_DROP
+#define INK_WIN_DROP 0x80000000u       // offset of a store the buffer bounds check drops (= the descriptor's num_records)
+#endif
 constexpr float NEG = -1e30f;
 constexpr float THR = 12.0f;
 // schedule knobs of `vm` (tools/win_variants.sh builds alternatives for same-box A/B runs)
@@ -250,6 +256,16 @@ __device__ __forceinline__ void sm_tail(Sub& u, float c, int n_k, int hh) {
 template <bool TOK>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void win4_attn_kernel(InkAttn p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // The kernel CLAIMS the SIMD's whole register file (512 = 256 VGPRs + 256 AGPRs; it uses 437): a wave of another
+  // kernel must never share a SIMD with one of these.  Found in round 3 (tools/coresidency_matrix.py):
+  // with this kernel on one stream and small kernels of another stream co-resident in the 72 registers it left over,
+  // those kernels read zeros in one register of one quarter-wave (groupnorm_apply_kernel: gamma.z of lanes 48..63 in
+  // 48 of 48 runs; the detector's boxes wrong in a third of back-to-back two-stream steps).  No store of this kernel
+  // leaves its output (tools/win_canary.py), its own results never change, the buffer-store bounds trick and the LDS
+  // size are not involved (variants built by tools/race_variants.sh); with the full claim: 0 of 80.
+#ifndef INK_EXP_PARTIAL_REGS      // (experiment switch of tools/race_variants.sh: the old behaviour)
+  asm volatile("v_accvgpr_write_b32 a255, %0" ::"v"(0) : "a255");
+#endif
   char* sK = smem;
   char* sV = smem + ROWS * KROW;
   int* sT = (int*)(smem + ROWS * KROW + ROWS * VROW);    // token rows of the window being fetched, [256]
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   int rt = fetch_row(blk + 1 < blk_end ? blk + 1 : last);
   load_q(blk, qrowA, qcA, A);
   load_q(blk, qrowB, qcB, B);
-  myOoff[lane] = 0x80000000u;                          // (no output rows staged yet: the first block's stores are dropped)
+  myOoff[lane] = INK_WIN_DROP;                          // (no output rows staged yet: the first block's stores are dropped)
 
   const float c = p.scale * 1.44269504088896340736f;
   const int koff0 = lq * KROW + hh * 16;
@@ -393,7 +409,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   // the loop top count the stores of the previous block instead of draining them)
 #pragma unroll
   for (int i = 0; i < 10; ++i)
-    __builtin_amdgcn_raw_buffer_store_b64((i32x2){0, 0}, orsrc, 0x80000000u, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64((i32x2){0, 0}, orsrc, INK_WIN_DROP, 0, 0);
 
   int nstamp = 0;
   (void)nstamp;
@@ -453,7 +469,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       const int idx = j * 64 + lane_x, row = idx / CH, ch = idx - row * CH;
       ov[j & 1] = *(const f16x8*)(myX + row * XROW + ch * 16);
       const uint32_t off = myOoff[row];
-      ooff[j & 1] = off == 0x80000000u ? off : off + (uint32_t)(ch * 16);
+      ooff[j & 1] = off == INK_WIN_DROP ? off : off + (uint32_t)(ch * 16);
     };
     auto xo_issue = [&](int j) {               // ... -> O (read one slot earlier: no LDS round trip inside a gap)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ov[j & 1]), orsrc, ooff[j & 1], 0, 0);
@@ -596,7 +612,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           }
         }
       const uint32_t o_row = TOK ? (uint32_t)qrow : (uint32_t)(b * p.n_q + qi);
-      if (hh == 0) myOoff[row0 + lq] = ok ? (o_row * (uint32_t)p.ldo + (uint32_t)(h * HD)) * 2u : 0x80000000u;
+      if (hh == 0) myOoff[row0 + lq] = ok ? (o_row * (uint32_t)p.ldo + (uint32_t)(h * HD)) * 2u : INK_WIN_DROP;
     };
     STAMP(9);
     if constexpr (!INK_WIN_QA_EARLY) {
@@ -618,7 +634,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const f16x8 v = *(const f16x8*)(myX + row * XROW + ch * 16);
     const uint32_t off = myOoff[row];
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4b, v), orsrc,
-                                           off == 0x80000000u ? off : off + (uint32_t)(ch * 16), 0, 0);
+                                           off == INK_WIN_DROP ? off : off + (uint32_t)(ch * 16), 0, 0);
   }
 }
 

@@ -33,12 +33,13 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows_out) return;
   const int nv = C >> 2;
+  const int64_t ldf = split ? ldo / 3 : ldo;      // f32 copy next to a split operand: rows of ldo / 3
   const int src = gather ? gather[row] : row;
   if (src < 0) {  // padded token: zeros (the reference pads AFTER the norm)
     for (int v = lane; v < nv; v += 64) {
       if (out_h && split) split_store(out_h + row * ldo + v * 4, C, (f32x4){0.f, 0.f, 0.f, 0.f});
       else if (out_h) *(f16x4*)(out_h + row * ldo + v * 4) = (f16x4){0, 0, 0, 0};
-      if (out_f) *(f32x4*)(out_f + row * ldo + v * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (out_f) *(f32x4*)(out_f + row * ldf + v * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     return;
   }
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
       }
       if (out_h && split) split_store(out_h + row * ldo + v * 4, C, y);
       else if (out_h) *(f16x4*)(out_h + row * ldo + v * 4) = (f16x4){(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
-      if (out_f) *(f32x4*)(out_f + row * ldo + v * 4) = y;
+      if (out_f) *(f32x4*)(out_f + row * ldf + v * 4) = y;
     }
   }
 }
@@ -206,7 +207,7 @@ extern "C" int ink_layernorm_rows(const float* x, int64_t ldx, const float* gamm
                                   const int32_t* add_batch_rows, int32_t rows_per_batch, void* stream) {
   INK_CHECK_ARG(x && (out_f16 || out_f32));
   INK_CHECK_ARG(!add || (!gather && rows_per_batch > 0 && ld_add >= C && ld_add % 4 == 0));
-  INK_CHECK_ARG(split == 0 || (split == 1 && out_f16 && !out_f32 && ldo >= 3 * (int64_t)C));
+  INK_CHECK_ARG(split == 0 || (split == 1 && out_f16 && ldo >= 3 * (int64_t)C && (!out_f32 || ldo % 12 == 0)));
   INK_CHECK_ARG(act == INK_ACT_NONE || act == INK_ACT_GELU);
   INK_CHECK_ARG(rows_out > 0 && C > 0 && C % 4 == 0 && C <= 2048);
   INK_CHECK_ARG(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= C && ldo >= C);

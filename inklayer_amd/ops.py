@@ -173,10 +173,12 @@ def layernorm_rows(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optiona
                    out_dtype: torch.dtype = F16, out: Optional[torch.Tensor] = None,
                    out2: Optional[torch.Tensor] = None, act: Optional[str] = None,
                    split: bool = False, add: Optional[torch.Tensor] = None,
-                   add_batch_rows: Optional[torch.Tensor] = None, rows_per_batch: int = 0) -> torch.Tensor:
+                   add_batch_rows: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
+                   split_f32: Optional[torch.Tensor] = None) -> torch.Tensor:
     """LayerNorm over the last dim of f32 x [R, C]; optional row gather (-1 -> zero row).
     `out2` (the other of f16/f32, same shape/stride) receives a second copy in the same pass.
-    split=True: the f16 output is a split-f16 GEMM operand [R, 3C] (see add_split_f16)."""
+    split=True: the f16 output is a split-f16 GEMM operand [R, 3C] (see add_split_f16); split_f32 (contiguous f32
+    [R, C]) then receives the f32 result in the same pass."""
     assert x.dtype == F32 and x.dim() == 2 and x.stride(1) == 1
     Cdim = x.shape[1]
     rows = gather.numel() if gather is not None else x.shape[0]
@@ -194,6 +196,10 @@ def layernorm_rows(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optiona
             oh = out2.data_ptr()
         else:
             of = out2.data_ptr()
+    if split_f32 is not None:
+        assert split and out.stride(0) == 3 * Cdim and split_f32.dtype == F32 and split_f32.is_contiguous()
+        assert tuple(split_f32.shape) == (rows, Cdim)
+        of = split_f32.data_ptr()
     if gather is not None:
         assert gather.dtype == torch.int32
     if add is not None:

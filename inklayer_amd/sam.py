@@ -639,6 +639,7 @@ class SamEngine:
         img_rows = _to_dev_async((iob * T).to(torch.int32), dev)
         keys = ops.add_f32(emb.reshape(B * T, E).contiguous(), w["no_mask"])      # [B*T, E], shared per image
         shared = True                                       # keys still one copy per IMAGE (layer 0)
+        ks = None                                           # split-f16 operand of the per-box keys (layers >= 1)
         queries = qpe
         sc32, sc16 = 1.0 / math.sqrt(32), 1.0 / math.sqrt(16)
 
@@ -665,7 +666,8 @@ class SamEngine:
                 queries = lin(SP(a), d + ".self.out_proj", residual=queries)
             queries = ops.layernorm_rows(queries, w[d + ".norm1.w"], w[d + ".norm1.b"], 1e-5, out_dtype=F32)
             # image-side projections of this layer from ONE split pass of the keys: [k_t2i | v_t2i | q_i2t]
-            kvq = ops.gemm(SP(keys), w[d + ".kvq.ws"], w[d + ".kvq.b"])             # [B*T or n*T, 384] f32
+            # (from layer 1 on the split operand was written by the LayerNorm that produced the keys)
+            kvq = ops.gemm(SP(keys) if ks is None else ks, w[d + ".kvq.ws"], w[d + ".kvq.b"])   # [B*T or n*T, 384] f32
             # (2) tokens -> image  (k = (keys + pe) Wk = kvq[:, :128] + pe Wk, added inside the attention)
             queries = ops.layernorm_rows(t2i_attend(d + ".t2i", queries, kvq[:, :Eh], kvq[:, Eh:2 * Eh],
                                                     w[d + ".t2i.k_pe"], queries),
@@ -679,16 +681,22 @@ class SamEngine:
             iv = lin(SP(queries), d + ".i2t.v_proj")
             a = ops.attn_fewkeys(kvq[:, 2 * Eh:], ik, iv, B=n, n_heads=Hh, head_dim=16, scale=sc16, n_q=T,
                                  q_batch_rows=img_rows if shared else None, q_add=w[d + ".i2t.q_pe"])   # [n*T, 128]
+            # norm4 writes the next consumer's split operand in the same pass (the keys feed only projections from here
+            # on); the f32 copy is kept only while a later layer still adds to it
+            last = i + 1 == cfg.dec_depth
             if shared:
                 # keys are still one copy per IMAGE: the residual add happens inside the LayerNorm through a per-box
                 # row gather - no per-box copy of the image keys (repeat_interleave of mask_decoder.py:124) is made
-                keys = ops.layernorm_rows(lin(SP(a), d + ".i2t.out_proj"), w[d + ".norm4.w"], w[d + ".norm4.b"], 1e-5,
-                                          out_dtype=F32, add=keys, add_batch_rows=img_rows, rows_per_batch=T)
+                y = lin(SP(a), d + ".i2t.out_proj")
+                keys_next = None if last else torch.empty_like(y)
+                ks = ops.layernorm_rows(y, w[d + ".norm4.w"], w[d + ".norm4.b"], 1e-5, split=True, add=keys,
+                                        add_batch_rows=img_rows, rows_per_batch=T, split_f32=keys_next)
                 shared = False
             else:
-                keys = ops.layernorm_rows(lin(SP(a), d + ".i2t.out_proj", residual=keys),
-                                          w[d + ".norm4.w"], w[d + ".norm4.b"], 1e-5, out_dtype=F32)
-        ks = SP(keys)
+                y = lin(SP(a), d + ".i2t.out_proj", residual=keys)
+                keys_next = None if last else y
+                ks = ops.layernorm_rows(y, w[d + ".norm4.w"], w[d + ".norm4.b"], 1e-5, split=True, split_f32=keys_next)
+            keys = keys_next
         kv = ops.gemm(ks, w["dfin.kv.ws"], w["dfin.kv.b"])
         queries = ops.layernorm_rows(t2i_attend("dfin", queries, kv[:, :Eh], kv[:, Eh:], w["dfin.k_pe"], queries),
                                      w["dfin.norm.w"], w["dfin.norm.b"], 1e-5, out_dtype=F32)
