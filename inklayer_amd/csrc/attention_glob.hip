@@ -191,6 +191,10 @@ __device__ __forceinline__ void sm_second(int g, Sub& u, float c) { sm_exp(8 + g
 
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void glob4_attn_kernel(InkAttn p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // claims the SIMD's whole register file like the window kernel (attention_win.hip: waves of other kernels sharing a
+  // SIMD with that kernel read corrupted registers; this one, same structure, showed nothing in tools/coresidency_matrix.py
+  // at its 453 registers - the 56 spare ones are not worth the exposure)
+  asm volatile("v_accvgpr_write_b32 a255, %0" ::"v"(0) : "a255");
   char* sRW = smem + 2 * TILE;                            // [256 queries][RWROW]
 
   const int tid = threadIdx.x, lane = tid & 63;

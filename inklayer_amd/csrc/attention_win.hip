@@ -263,9 +263,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   // 48 of 48 runs; the detector's boxes wrong in a third of back-to-back two-stream steps).  No store of this kernel
   // leaves its output (tools/win_canary.py), its own results never change, the buffer-store bounds trick and the LDS
   // size are not involved (variants built by tools/race_variants.sh); with the full claim: 0 of 80.
-#ifndef INK_EXP_PARTIAL_REGS      // (experiment switch of tools/race_variants.sh: the old behaviour)
-  asm volatile("v_accvgpr_write_b32 a255, %0" ::"v"(0) : "a255");
+#ifndef INK_EXP_CLAIM_AGPR         // (experiment switch of tools/race_variants.sh: claim up to another AGPR; 180 = old behaviour)
+#define INK_EXP_CLAIM_AGPR 255
 #endif
+#define INK_STR2(x) #x
+#define INK_STR(x) INK_STR2(x)
+  asm volatile("v_accvgpr_write_b32 a" INK_STR(INK_EXP_CLAIM_AGPR) ", %0" ::"v"(0) : "a" INK_STR(INK_EXP_CLAIM_AGPR));
   char* sK = smem;
   char* sV = smem + ROWS * KROW;
   int* sT = (int*)(smem + ROWS * KROW + ROWS * VROW);    // token rows of the window being fetched, [256]
@@ -407,9 +410,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   // (hipcc merges the memory-counter state of the loop entry with the back edge's and waits for the smaller count:
   // ten dropped stores here give the entry the block loop's own issue order - rows, Q', stores - so the waits at
   // the loop top count the stores of the previous block instead of draining them)
+#ifndef INK_EXP_GLOBAL_STORES
 #pragma unroll
   for (int i = 0; i < 10; ++i)
     __builtin_amdgcn_raw_buffer_store_b64((i32x2){0, 0}, orsrc, INK_WIN_DROP, 0, 0);
+#endif
 
   int nstamp = 0;
   (void)nstamp;
@@ -472,7 +477,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       ooff[j & 1] = off == INK_WIN_DROP ? off : off + (uint32_t)(ch * 16);
     };
     auto xo_issue = [&](int j) {               // ... -> O (read one slot earlier: no LDS round trip inside a gap)
+#ifdef INK_EXP_GLOBAL_STORES       // (experiment of tools/race_variants.sh: masked global stores instead of buffer stores)
+      if (ooff[j & 1] < 0x80000000u) *(i32x4*)((char*)p.O + ooff[j & 1]) = __builtin_bit_cast(i32x4, ov[j & 1]);
+#else
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ov[j & 1]), orsrc, ooff[j & 1], 0, 0);
+#endif
     };
     // The block's vector-memory instructions, spread over its 166 MFMA gaps (G = gap number in the block, a
     // compile-time constant after unrolling).  Back to back they overflow the CU's vector-memory queue (4 waves x 19
@@ -633,8 +642,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int idx = j * 64 + lane, row = idx / CH, ch = idx - row * CH;
     const f16x8 v = *(const f16x8*)(myX + row * XROW + ch * 16);
     const uint32_t off = myOoff[row];
+#ifdef INK_EXP_GLOBAL_STORES
+    if (off != INK_WIN_DROP) *(i32x4b*)((char*)p.O + off + (uint32_t)(ch * 16)) = __builtin_bit_cast(i32x4b, v);
+#else
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4b, v), orsrc,
                                            off == INK_WIN_DROP ? off : off + (uint32_t)(ch * 16), 0, 0);
+#endif
   }
 }
 
