@@ -576,6 +576,28 @@ def fusion_fold(v: torch.Tensor, B: int, S: int, lnv_g: torch.Tensor, lnv_b: tor
     return out_l
 
 
+def sam_upscale_pack(ws: torch.Tensor) -> torch.Tensor:
+    """output_upscaling.3 as the split-f16 matrix [128, 192] -> the LDS image of sam_upscale_tail (load time)."""
+    assert ws.dtype == F16 and ws.is_contiguous() and tuple(ws.shape) == (128, 192)
+    blob = torch.empty(4 * 12 * 64 * 8, device=ws.device, dtype=F16)
+    check(_lib.lib().ink_sam_upscale_pack(ws.data_ptr(), blob.data_ptr(), _stream()), "ink_sam_upscale_pack")
+    return blob
+
+
+def sam_upscale_tail(u0: torch.Tensor, n: int, g: int, ln_g: torch.Tensor, ln_b: torch.Tensor, eps: float,
+                     blob: torch.Tensor, b3: torch.Tensor, hyper: torch.Tensor) -> torch.Tensor:
+    """LayerNorm2d + GELU + ConvTranspose2d(k2 s2) + GELU + hyper-network product of the mask decoder in one kernel
+    (mask_decoder.py:54-60, 138-145): u0 f32 [n*g*g*4, 64] -> low-res mask logits f32 [n, 4g, 4g]."""
+    assert u0.dtype == F32 and u0.is_contiguous() and tuple(u0.shape) == (n * g * g * 4, 64)
+    assert blob.dtype == F16 and blob.numel() == 4 * 12 * 64 * 8 and b3.dtype == F32 and b3.numel() == 128
+    assert hyper.dtype == F32 and hyper.is_contiguous() and tuple(hyper.shape) == (n, 32)
+    assert ln_g.dtype == F32 and ln_b.dtype == F32 and ln_g.numel() == 64 and ln_b.numel() == 64
+    low = torch.empty((n, 4 * g, 4 * g), device=u0.device, dtype=F32)
+    check(_lib.lib().ink_sam_upscale_tail(u0.data_ptr(), n, g, ln_g.data_ptr(), ln_b.data_ptr(), eps, blob.data_ptr(),
+                                          b3.data_ptr(), hyper.data_ptr(), low.data_ptr(), _stream()), "ink_sam_upscale_tail")
+    return low
+
+
 def ffn256_pack(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     """linear1.weight f16 [hid, 256] + linear1.bias f32 [hid] + linear2.weight f16 [256, hid] -> the packed weight blob of
     ffn256_fused (done once at load time; csrc/ffn_fused.hip)."""

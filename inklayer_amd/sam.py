@@ -298,6 +298,8 @@ class SamEngine:
         u = "mask_decoder.output_upscaling."
         w["up0.ws"] = ops.split_weight(m(u + "0.weight").permute(2, 3, 1, 0).reshape(4 * (E // 4), E))
         w["up3.ws"] = ops.split_weight(m(u + "3.weight").permute(2, 3, 1, 0).reshape(4 * (E // 8), E // 4))
+        if self.fuse_upscale_tail and tuple(w["up3.ws"].shape) == (128, 192):
+            w["up3.blob"] = ops.sam_upscale_pack(w["up3.ws"].contiguous())          # csrc/upscale_tail.hip
         for j in range(3):
             w[f"hyp{j}.ws"] = ops.split_weight(m(f"mask_decoder.output_hypernetworks_mlps.0.layers.{j}.weight"))
             w[f"iou{j}.ws"] = ops.split_weight(m(f"mask_decoder.iou_prediction_head.layers.{j}.weight"))
@@ -370,6 +372,7 @@ class SamEngine:
     # size is captured the second time it is seen (a capture costs three forwards and pins a private pool for the
     # neck's intermediates); the result is cloned out of that pool.
     graph_blocks = False
+    fuse_upscale_tail = True     # LayerNorm2d + GELU + ConvT + GELU + hyper product as one kernel (csrc/upscale_tail.hip)
     graph_cache_size = 2
 
     def _blocks_graphed(self, B: int) -> torch.Tensor:
@@ -710,9 +713,15 @@ class SamEngine:
         hyper = mlp3("hyp", hs[:, 1].contiguous())          # mask token 0 -> [n, 32]
         iou = mlp3("iou", hs[:, 0].contiguous())[:, :1]     # iou token -> [n, 4] -> mask 0
         u0 = lin(ks, "up0")                                                      # [n*T, 4*64]
-        u1 = ops.layernorm_rows(u0.view(n * T * 4, E // 4), w["up1.w"], w["up1.b"], 1e-6, act="gelu", split=True)
-        u2 = lin(u1, "up3", act="gelu")                                          # [n*T*4, 4*32]
-        low = ops.sam_mask_logits(u2, hyper.contiguous(), n, g)                   # [n, 256, 256]
+        if "up3.blob" in w and (T * 4) % 32 == 0:
+            # LayerNorm2d + GELU + the second transposed convolution + GELU + the hyper-network product in one kernel
+            # (csrc/upscale_tail.hip): u0 is read once, 4 floats per row are written
+            low = ops.sam_upscale_tail(u0.view(n * T * 4, E // 4), n, g, w["up1.w"], w["up1.b"], 1e-6, w["up3.blob"],
+                                       w["up3.b"], hyper.contiguous())
+        else:
+            u1 = ops.layernorm_rows(u0.view(n * T * 4, E // 4), w["up1.w"], w["up1.b"], 1e-6, act="gelu", split=True)
+            u2 = lin(u1, "up3", act="gelu")                                          # [n*T*4, 4*32]
+            low = ops.sam_mask_logits(u2, hyper.contiguous(), n, g)                   # [n, 256, 256]
         return low, iou
 
 

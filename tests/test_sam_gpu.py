@@ -264,3 +264,34 @@ def test_engine_leaves_the_state_dict_untouched_and_bias_correction_helps(dev):
     e_plain = _rel(plain.encode([dimg], upto=4)[0], ref)[1]
     print(f"4 blocks on a sketch: l2-rel {e_plain:.2e} plain f16 weights, {e_corr:.2e} with the bias correction")
     assert e_corr < 0.85 * e_plain
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("n,g", [(3, 16), (2, 64), (5, 4)])
+def test_upscale_tail_kernel_equals_the_three_kernel_form(dev, n, g):
+    """ops.sam_upscale_tail (csrc/upscale_tail.hip) = LayerNorm2d + GELU + ConvTranspose2d(k2 s2) + GELU + hyper-network
+    product (mask_decoder.py:54-60, 138-145) against float64 and against the three-kernel form it replaces
+    (layernorm_rows(split) + split GEMM + sam_mask_logits)."""
+    from inklayer_amd import ops
+    gen = torch.Generator().manual_seed(100 * n + g)
+    T = g * g
+    u0 = torch.randn(n * T * 4, 64, generator=gen) * 1.7 + 0.2
+    w3 = torch.randn(128, 64, generator=gen) / 8                      # rows (s2, c)
+    b3 = (torch.randn(32, generator=gen) * 0.3).repeat(4)
+    lg, lb = 1 + 0.2 * torch.randn(64, generator=gen), 0.2 * torch.randn(64, generator=gen)
+    hyper = torch.randn(n, 32, generator=gen)
+    gelu = torch.nn.functional.gelu
+    a = gelu(torch.nn.functional.layer_norm(u0.double(), (64,), lg.double(), lb.double(), 1e-6))
+    up = gelu(a @ w3.double().t() + b3.double()).view(n, g, g, 2, 2, 2, 2, 32)          # [b, y, x, s1y, s1x, s2y, s2x, c]
+    val = (up * hyper.double().view(n, 1, 1, 1, 1, 1, 1, 32)).sum(-1)
+    want = val.permute(0, 1, 3, 5, 2, 4, 6).reshape(n, 4 * g, 4 * g)                  # Y = 4y + 2 s1y + s2y, X alike
+    d = lambda t: t.to(dev).contiguous()
+    ws = ops.split_weight(d(w3))
+    low = ops.sam_upscale_tail(d(u0), n, g, d(lg), d(lb), 1e-6, ops.sam_upscale_pack(ws), d(b3), d(hyper))
+    err = ((low.double().cpu() - want).abs().max() / want.abs().max()).item()
+    u1 = ops.layernorm_rows(d(u0), d(lg), d(lb), 1e-6, act="gelu", split=True)
+    u2 = ops.gemm(u1, ws, d(b3), act="gelu")
+    three = ops.sam_mask_logits(u2, d(hyper), n, g)
+    err3 = ((low - three).abs().max() / three.abs().max()).item()
+    print(f"n={n} g={g}: fused tail vs float64 max-rel {err:.2e}, vs the three-kernel form {err3:.2e}")
+    assert err < 5e-6 and err3 < 5e-6
