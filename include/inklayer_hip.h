@@ -333,12 +333,12 @@ int ink_fusion_fold(float* v_f32, int32_t B, int32_t S, const float* lnv_g, cons
 
 /* Tail of the SAM mask decoder in one kernel (csrc/upscale_tail.hip): LayerNorm2d + GELU + the second ConvTranspose2d
  * (k2 s2 = a [64 -> 4 x 32] projection per row) + GELU + the hyper-network product of mask token 0
- * (SA/modeling/mask_decoder.py:54-60, 138-145).  u0 f32 [n * g*g * 4, 64]: the first transposed convolution's output, row
- * (box, token, sub-pixel s1); ln_g / ln_b f32 [64] (output_upscaling.1), eps 1e-6; blob: output_upscaling.3.weight as the
+ * (SA/modeling/mask_decoder.py:54-60, 138-145).  u0 f32: the first transposed convolution's output, 4 x 64 floats per
+ * (box, token) at token stride ld_tok (>= 256 floats: it may be a column block of a wider projection), row (token, s1); ln_g / ln_b f32 [64] (output_upscaling.1), eps 1e-6; blob: output_upscaling.3.weight as the
  * split-f16 matrix [128, 192] (rows (s2, c), see ink_add_split_f16) packed by ink_sam_upscale_pack (48 KiB); b3 f32 [128]
  * (the bias repeated per sub-pixel); hyper f32 [n, 32]; low f32 [n, 4g, 4g].  (g*g*4) % 32 == 0. */
 int ink_sam_upscale_pack(const void* ws_f16, void* blob_f16, void* stream);
-int ink_sam_upscale_tail(const float* u0, int32_t n, int32_t g, const float* ln_g, const float* ln_b, float eps,
+int ink_sam_upscale_tail(const float* u0, int64_t ld_tok, int32_t n, int32_t g, const float* ln_g, const float* ln_b, float eps,
                          const void* blob_f16, const float* b3, const float* hyper, float* low, void* stream);
 
 /* Feed-forward block of the deformable encoder layer, fused (csrc/ffn_fused.hip):

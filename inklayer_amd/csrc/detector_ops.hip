@@ -442,6 +442,55 @@ __global__ __launch_bounds__(256) void attn_fewkeys_kernel(const T* __restrict__
 }
 
 
+// head_dim 16, f32 rows (the SAM decoder's image->token attention: 4096 queries x 7 keys per box, 8 heads): FOUR lanes
+// per (query, head), 4 of the 16 dimensions each, so that every load and store instruction of a wave covers one
+// contiguous KiB (a thread per (query, head) reads 64 B at a 64-B stride: every cache line is touched by four
+// instructions); the four partial dot products meet through two shuffles.  Base-2 softmax (log2 e folded into the scale).
+__global__ __launch_bounds__(256) void attn_fewkeys16_f32_kernel(const float* __restrict__ Q, int64_t ldq,
+                                                                 const float* __restrict__ K, int64_t ldk,
+                                                                 const float* __restrict__ V, int64_t ldv, int B,
+                                                                 int n_q, int n_k, int n_heads, float scale,
+                                                                 const int32_t* __restrict__ q_rows,
+                                                                 const float* __restrict__ q_add,
+                                                                 float* __restrict__ O, int64_t ldo) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)B * n_q * n_heads * 4) return;      // (whole 4-lane groups: the total is a multiple of 4)
+  const int part = (int)(gid & 3);
+  const int h = (int)((gid >> 2) % n_heads);
+  const int64_t bq = (gid >> 2) / n_heads;
+  const int b = (int)(bq / n_q), q = (int)(bq % n_q);
+  const int col = h * 16 + 4 * part;
+  f32x4 qv = *(const f32x4*)(Q + (q_rows ? (int64_t)q_rows[b] + q : bq) * ldq + col);
+  if (q_add) qv += *(const f32x4*)(q_add + (int64_t)q * n_heads * 16 + col);
+  qv *= scale * 1.44269504088896340736f;
+  float sc[16];                                            // n_k <= 16; uniform guards keep the indices compile-time
+  float mx = -3.0e38f;
+  const float* kp = K + (int64_t)b * n_k * ldk + col;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    sc[t] = -3.0e38f;
+    if (t < n_k) {
+      const f32x4 kv = *(const f32x4*)(kp + (int64_t)t * ldk);
+      float d = (qv[0] * kv[0] + qv[1] * kv[1]) + (qv[2] * kv[2] + qv[3] * kv[3]);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      sc[t] = d;
+      mx = fmaxf(mx, d);
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (t < n_k) { sc[t] = __builtin_amdgcn_exp2f(sc[t] - mx); sum += sc[t]; }
+  const float inv = 1.f / sum;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* vp = V + (int64_t)b * n_k * ldv + col;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (t < n_k) acc += (sc[t] * inv) * *(const f32x4*)(vp + (int64_t)t * ldv);
+  *(f32x4*)(O + bq * ldo + col) = acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Attention of a FEW queries (n_q <= 8) against many keys: SAM decoder token->image attention
 // (7 tokens x 4096 image keys, 8 heads x 16; SA/modeling/transformer.py:163-168, 101-103).
@@ -520,8 +569,8 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const f16* __restrict__ 
 // a key row's 4-head slice is exactly one 128-B line, 64-key K/V tiles are staged through LDS with 16-byte loads
 // (each byte fetched once per workgroup), wave w owns queries 2w and 2w+1, lane (kl = lane / 4, hl = lane % 4)
 // streams keys kl, kl+16, ... of head hl, and the 16 key-lanes of a head are merged with in-wave shuffles.
-template <typename T>
-__global__ __launch_bounds__(256) void attn_fewq16_kernel(const T* __restrict__ Q, int64_t ldq,
+template <typename T, int KSPLIT>
+__global__ __launch_bounds__(256 * KSPLIT) void attn_fewq16_kernel(const T* __restrict__ Q, int64_t ldq,
                                                           const T* __restrict__ K, int64_t ldk,
                                                           const T* __restrict__ V, int64_t ldv, int n_q,
                                                           int n_k, int n_heads, float scale,
@@ -529,15 +578,24 @@ __global__ __launch_bounds__(256) void attn_fewq16_kernel(const T* __restrict__ 
                                                           const int32_t* __restrict__ kv_rows,
                                                           const float* __restrict__ k_add,
                                                           T* __restrict__ O, int64_t ldo) {
+  // KSPLIT groups of four waves share the key range (group g streams keys [g, g + 1) * n_k / KSPLIT through its own LDS
+  // tiles; the partial softmax states meet in LDS at the end): the launch is only n_batch x n_heads / 4 workgroups - one
+  // per CU for 128 boxes - and one wave per SIMD leaves every LDS and memory latency exposed (round 3: 268 us for
+  // 4096 keys x 128 boxes at KSPLIT = 1, whatever the tile size or prefetch depth).
   constexpr int HD = 16, HB = 4, TK = 64;
   constexpr int ROWE = HB * HD;                      // elements of K (or V) per key and 4-head group (one 128-B line in f16)
   constexpr int CH = 16 / (int)sizeof(T);            // elements per 16-byte chunk
   constexpr int NCH = ROWE / CH;                     // chunks per row: 8 (f16) / 16 (f32)
   constexpr int NU = TK * NCH / 256;                 // chunks per thread and operand: 2 / 4
-  __shared__ __attribute__((aligned(16))) T sk[TK * ROWE], sv[TK * ROWE];
+  extern __shared__ __attribute__((aligned(16))) char fewq_smem[];
+  const int grp = threadIdx.x >> 8;                  // key-range group of this wave
+  T* sk = (T*)fewq_smem + grp * 2 * TK * ROWE;
+  T* sv = sk + TK * ROWE;
   const int hgroups = n_heads / HB;
   const int b = blockIdx.x / hgroups, h0 = (blockIdx.x % hgroups) * HB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int per = ((n_k + KSPLIT - 1) / KSPLIT + TK - 1) / TK * TK;      // keys per group, whole tiles
+  const int k_lo = grp * per, k_hi = min(n_k, k_lo + per);
   const int kl = lane >> 2, hl = lane & 3;
   const int64_t q0 = q_rows ? (int64_t)q_rows[b] : (int64_t)b * n_q;
   const int64_t k0 = kv_rows ? (int64_t)kv_rows[b] : (int64_t)b * n_k;
@@ -551,21 +609,24 @@ __global__ __launch_bounds__(256) void attn_fewq16_kernel(const T* __restrict__ 
       load8(pa + 8 * i, qA + 8 * i);
       load8(pb + 8 * i, qB + 8 * i);
     }
+    const float sc2 = scale * 1.44269504088896340736f;       // scores in log2 units: exp2 below
 #pragma unroll
-    for (int j = 0; j < HD; ++j) { qA[j] *= scale; qB[j] *= scale; }
+    for (int j = 0; j < HD; ++j) { qA[j] *= sc2; qB[j] *= sc2; }
   }
   float mA = -3.0e38f, lA = 0.f, mB = -3.0e38f, lB = 0.f, aA[HD], aB[HD];
 #pragma unroll
   for (int i = 0; i < HD; ++i) aA[i] = aB[i] = 0.f;
-  // staging: TK rows x NCH chunks of 16 B per operand; thread t moves chunks t, t + 256, ...
+  // staging: TK rows x NCH chunks of 16 B per operand; thread t moves chunks t, t + 256, ...  The NEXT tile's chunks are
+  // loaded into registers before the current tile is computed (round 3: without that every one of the n_k / 64 tiles
+  // exposed a full memory round trip - 268 us for 4096 keys, of which the arithmetic is ~100).
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  for (int t0 = 0; t0 < n_k; t0 += TK) {
-    u32x4 rk[NU], rv[NU];
+  u32x4 rk[NU], rv[NU];
+  auto fetch = [&](int t0) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int c = tid + 256 * u, row = c / NCH, col = c % NCH;
       rk[u] = rv[u] = (u32x4){0u, 0u, 0u, 0u};
-      if (t0 + row < n_k) {
+      if (t0 + row < k_hi) {
         rk[u] = *(const u32x4*)(K + (k0 + t0 + row) * ldk + h0 * HD + col * CH);
         rv[u] = *(const u32x4*)(V + (k0 + t0 + row) * ldv + h0 * HD + col * CH);
         if constexpr (sizeof(T) == 4) {
@@ -578,6 +639,9 @@ __global__ __launch_bounds__(256) void attn_fewq16_kernel(const T* __restrict__ 
         }
       }
     }
+  };
+  fetch(k_lo);
+  for (int t0 = k_lo; t0 < k_lo + per; t0 += TK) {       // every group runs the same number of tiles: shared barriers
     __syncthreads();                                   // previous tile consumed
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -586,35 +650,48 @@ __global__ __launch_bounds__(256) void attn_fewq16_kernel(const T* __restrict__ 
       *(u32x4*)(sv + row * ROWE + col * CH) = rv[u];
     }
     __syncthreads();
+    if (t0 + TK < k_hi) fetch(t0 + TK);                // in flight under this tile's arithmetic
+    // scores of the lane's four keys of this tile (base-2 exponent units: log2(e) is folded into the query scale), ONE
+    // rescale of the running sums per tile and query
+    float dA[TK / 16], dB[TK / 16];
 #pragma unroll
     for (int kk = 0; kk < TK / 16; ++kk) {
       const int key = kk * 16 + kl;
-      float kf[HD], vf[HD];
+      float kf[HD];
       load8(sk + key * ROWE + hl * HD, kf);
       load8(sk + key * ROWE + hl * HD + 8, kf + 8);
-      load8(sv + key * ROWE + hl * HD, vf);
-      load8(sv + key * ROWE + hl * HD + 8, vf + 8);
-      float dA = 0.f, dB = 0.f;
+      float a0 = 0.f, b0 = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        dA = fmaf(qA[j], kf[j], dA); dA = fmaf(qA[8 + j], kf[8 + j], dA);
-        dB = fmaf(qB[j], kf[j], dB); dB = fmaf(qB[8 + j], kf[8 + j], dB);
+        a0 = fmaf(qA[j], kf[j], a0); a0 = fmaf(qA[8 + j], kf[8 + j], a0);
+        b0 = fmaf(qB[j], kf[j], b0); b0 = fmaf(qB[8 + j], kf[8 + j], b0);
       }
-      if (t0 + key >= n_k) { dA = -3.0e38f; dB = -3.0e38f; }
-      {
-        const float mn = fmaxf(mA, dA), a = expf(mA - mn), pw = (t0 + key < n_k) ? expf(dA - mn) : 0.f;
-        lA = lA * a + pw;
+      const bool in = t0 + key < k_hi;
+      dA[kk] = in ? a0 : -3.0e38f;
+      dB[kk] = in ? b0 : -3.0e38f;
+    }
+    float nA = mA, nB = mB;
 #pragma unroll
-        for (int j = 0; j < HD; ++j) aA[j] = fmaf(pw, vf[j], aA[j] * a);
-        mA = mn;
-      }
-      {
-        const float mn = fmaxf(mB, dB), a = expf(mB - mn), pw = (t0 + key < n_k) ? expf(dB - mn) : 0.f;
-        lB = lB * a + pw;
+    for (int kk = 0; kk < TK / 16; ++kk) { nA = fmaxf(nA, dA[kk]); nB = fmaxf(nB, dB[kk]); }
+    const float sA = __builtin_amdgcn_exp2f(mA - nA), sB = __builtin_amdgcn_exp2f(mB - nB);
+    lA *= sA;
+    lB *= sB;
 #pragma unroll
-        for (int j = 0; j < HD; ++j) aB[j] = fmaf(pw, vf[j], aB[j] * a);
-        mB = mn;
-      }
+    for (int j = 0; j < HD; ++j) { aA[j] *= sA; aB[j] *= sB; }
+    mA = nA;
+    mB = nB;
+#pragma unroll
+    for (int kk = 0; kk < TK / 16; ++kk) {
+      const int key = kk * 16 + kl;
+      float vf[HD];
+      load8(sv + key * ROWE + hl * HD, vf);
+      load8(sv + key * ROWE + hl * HD + 8, vf + 8);
+      const bool in = t0 + key < k_hi;
+      const float pA = in ? __builtin_amdgcn_exp2f(dA[kk] - nA) : 0.f, pB = in ? __builtin_amdgcn_exp2f(dB[kk] - nB) : 0.f;
+      lA += pA;
+      lB += pB;
+#pragma unroll
+      for (int j = 0; j < HD; ++j) { aA[j] = fmaf(pA, vf[j], aA[j]); aB[j] = fmaf(pB, vf[j], aB[j]); }
     }
   }
   auto merge = [&](float& m, float& l, float (&acc)[HD]) {
@@ -622,7 +699,7 @@ __global__ __launch_bounds__(256) void attn_fewq16_kernel(const T* __restrict__ 
     for (int o = 4; o < 64; o <<= 1) {               // the 16 key-lanes of this head: lane bits 2..5
       const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
       const float mn = fmaxf(m, mo);
-      const float a = expf(m - mn), bsc = expf(mo - mn);
+      const float a = __builtin_amdgcn_exp2f(m - mn), bsc = __builtin_amdgcn_exp2f(mo - mn);
       l = l * a + lo * bsc;
 #pragma unroll
       for (int i = 0; i < HD; ++i) acc[i] = acc[i] * a + __shfl_xor(acc[i], o, 64) * bsc;
@@ -631,6 +708,36 @@ __global__ __launch_bounds__(256) void attn_fewq16_kernel(const T* __restrict__ 
   };
   merge(mA, lA, aA);
   merge(mB, lB, aB);
+  if constexpr (KSPLIT > 1) {
+    // groups 1.. park their states (m, l, acc[16]) per (wave, query slot, head lane) in LDS; group 0 folds them in
+    __syncthreads();                                     // the last tiles are consumed: the K/V tiles can be overwritten
+    float* st = (float*)fewq_smem;
+    if (grp > 0 && kl == 0) {
+      float* pa = st + ((((grp - 1) * 4 + wave) * 2 + 0) * 4 + hl) * 18;
+      float* pb = st + ((((grp - 1) * 4 + wave) * 2 + 1) * 4 + hl) * 18;
+      pa[0] = mA; pa[1] = lA; pb[0] = mB; pb[1] = lB;
+#pragma unroll
+      for (int i = 0; i < HD; ++i) { pa[2 + i] = aA[i]; pb[2 + i] = aB[i]; }
+    }
+    __syncthreads();
+    if (grp > 0) return;
+    if (kl == 0) {
+#pragma unroll
+      for (int g2 = 1; g2 < KSPLIT; ++g2) {
+        auto fold = [&](int slot, float& m, float& l, float (&acc)[HD]) {
+          const float* ps = st + ((((g2 - 1) * 4 + wave) * 2 + slot) * 4 + hl) * 18;
+          const float mo = ps[0], mn = fmaxf(m, mo);
+          const float a = __builtin_amdgcn_exp2f(m - mn), bsc = __builtin_amdgcn_exp2f(mo - mn);
+          l = l * a + ps[1] * bsc;
+#pragma unroll
+          for (int i = 0; i < HD; ++i) acc[i] = acc[i] * a + ps[2 + i] * bsc;
+          m = mn;
+        };
+        fold(0, mA, lA, aA);
+        fold(1, mB, lB, aB);
+      }
+    }
+  }
   if (kl == 0) {
     auto put = [&](int q, float l, float (&acc)[HD]) {
       if (q < n_q) {
@@ -859,7 +966,12 @@ extern "C" int ink_attn_fewkeys(const void* Q, int64_t ldq, const void* K, int64
   else if (head_dim == 64 && !io_f32) INK_FEWKEYS(64, f16);
   else if (head_dim == 16 && !io_f32) INK_FEWKEYS(16, f16);
   else if (head_dim == 32) INK_FEWKEYS(32, float);
-  else if (head_dim == 16) INK_FEWKEYS(16, float);
+  else if (head_dim == 16 && !blocked && n_k <= 16) {
+    const int64_t t4 = total * 4;
+    hipLaunchKernelGGL(attn_fewkeys16_f32_kernel, dim3((unsigned)((t4 + 255) / 256)), block, 0, s, (const float*)Q, ldq,
+                       (const float*)K, ldk, (const float*)V, ldv, B, n_q, n_k, n_heads, scale, q_batch_rows, q_add,
+                       (float*)O, ldo);
+  } else if (head_dim == 16) INK_FEWKEYS(16, float);
   else return INK_ERR_ARG;
 #undef INK_FEWKEYS
   return ink_launch_status();
@@ -876,11 +988,15 @@ extern "C" int ink_attn_fewq(const void* Q, int64_t ldq, const void* K, int64_t 
   const dim3 grid(n_batch * n_heads), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (head_dim == 16 && n_heads % 4 == 0 && io_f32) {
-    hipLaunchKernelGGL(attn_fewq16_kernel<float>, dim3(n_batch * (n_heads / 4)), block, 0, s, (const float*)Q, ldq,
+    constexpr int lds = 2 * 2 * 64 * 64 * 4;           // two key-range groups x (K, V) tiles of 64 keys x 4 heads x 16 f32
+    static bool attr = ((void)hipFuncSetAttribute((const void*)attn_fewq16_kernel<float, 2>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+    (void)attr;
+    hipLaunchKernelGGL((attn_fewq16_kernel<float, 2>), dim3(n_batch * (n_heads / 4)), dim3(512), lds, s, (const float*)Q, ldq,
                        (const float*)K, ldk, (const float*)V, ldv, n_q, n_k, n_heads, scale, q_batch_rows,
                        kv_batch_rows, k_add, (float*)O, ldo);
   } else if (head_dim == 16 && n_heads % 4 == 0) {
-    hipLaunchKernelGGL(attn_fewq16_kernel<f16>, dim3(n_batch * (n_heads / 4)), block, 0, s, (const f16*)Q, ldq,
+    hipLaunchKernelGGL((attn_fewq16_kernel<f16, 1>), dim3(n_batch * (n_heads / 4)), block, 2 * 64 * 64 * 2, s, (const f16*)Q, ldq,
                        (const f16*)K, ldk, (const f16*)V, ldv, n_q, n_k, n_heads, scale, q_batch_rows, kv_batch_rows,
                        (const float*)nullptr, (f16*)O, ldo);
   } else if (head_dim == 16) {

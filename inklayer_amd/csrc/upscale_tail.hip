@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void upscale_pack_kernel(const f16* __restrict
   *(f16x8*)(blob + (int64_t)idx * 8) = *(const f16x8*)(ws + (int64_t)(32 * jt + (lane & 31)) * (3 * CI) + 16 * s + 8 * (lane >> 5));
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void upscale_tail_kernel(const float* __restrict__ u0, int64_t n_tiles,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void upscale_tail_kernel(const float* __restrict__ u0, int64_t ld_tok, int64_t n_tiles,
                                                            const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                            float eps, const f16* __restrict__ blob,
                                                            const float* __restrict__ b3, const float* __restrict__ hyper,
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("" ::: "memory");      // the 48 weight fragments are re-read from LDS per tile: hoisted out of the loop they take 192 registers
     const int64_t row = t * 32 + l;
     // ---- the lane's half of its row: channels 16 s' + 8 hh + 0..7, s' = 0..3
-    const float* xp = u0 + row * CI + 8 * hh;
+    const float* xp = u0 + (row >> 2) * ld_tok + (row & 3) * CI + 8 * hh;      // row = (token, sub-pixel s1)
     f32x4 x[8];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -144,16 +144,17 @@ extern "C" int ink_sam_upscale_pack(const void* ws_f16, void* blob_f16, void* st
   return ink_launch_status();
 }
 
-extern "C" int ink_sam_upscale_tail(const float* u0, int32_t n, int32_t g, const float* ln_g, const float* ln_b, float eps,
+extern "C" int ink_sam_upscale_tail(const float* u0, int64_t ld_tok, int32_t n, int32_t g, const float* ln_g, const float* ln_b, float eps,
                                     const void* blob_f16, const float* b3, const float* hyper, float* low, void* stream) {
   INK_CHECK_ARG(u0 && ln_g && ln_b && blob_f16 && b3 && hyper && low && n > 0 && g > 0 && (g * g * 4) % 32 == 0);
+  INK_CHECK_ARG(ld_tok >= 4 * CI && ld_tok % 4 == 0);
   INK_CHECK_ARG((((uintptr_t)u0 | (uintptr_t)blob_f16 | (uintptr_t)hyper | (uintptr_t)low) & 15) == 0);
   static bool attr = ((void)hipFuncSetAttribute((const void*)upscale_tail_kernel,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), true);
   (void)attr;
   const int64_t n_tiles = (int64_t)n * g * g * 4 / 32;
   const int grid = (int)(n_tiles / 4 < 1024 ? (n_tiles + 3) / 4 : 1024);
-  hipLaunchKernelGGL(upscale_tail_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, u0, n_tiles, ln_g, ln_b,
+  hipLaunchKernelGGL(upscale_tail_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, u0, ld_tok, n_tiles, ln_g, ln_b,
                      eps, (const f16*)blob_f16, b3, hyper, g, low);
   return ink_launch_status();
 }

@@ -587,13 +587,17 @@ def sam_upscale_pack(ws: torch.Tensor) -> torch.Tensor:
 def sam_upscale_tail(u0: torch.Tensor, n: int, g: int, ln_g: torch.Tensor, ln_b: torch.Tensor, eps: float,
                      blob: torch.Tensor, b3: torch.Tensor, hyper: torch.Tensor) -> torch.Tensor:
     """LayerNorm2d + GELU + ConvTranspose2d(k2 s2) + GELU + hyper-network product of the mask decoder in one kernel
-    (mask_decoder.py:54-60, 138-145): u0 f32 [n*g*g*4, 64] -> low-res mask logits f32 [n, 4g, 4g]."""
-    assert u0.dtype == F32 and u0.is_contiguous() and tuple(u0.shape) == (n * g * g * 4, 64)
+    (mask_decoder.py:54-60, 138-145): u0 f32 [n*g*g, 256] (4 sub-pixels x 64 channels per token; rows may be a column
+    block of a wider tensor) or [n*g*g*4, 64] contiguous -> low-res mask logits f32 [n, 4g, 4g]."""
+    if u0.shape[1] == 64:
+        assert u0.is_contiguous() and u0.shape[0] == n * g * g * 4
+        u0 = u0.view(n * g * g, 256)
+    assert u0.dtype == F32 and u0.stride(1) == 1 and tuple(u0.shape) == (n * g * g, 256) and u0.stride(0) % 4 == 0
     assert blob.dtype == F16 and blob.numel() == 4 * 12 * 64 * 8 and b3.dtype == F32 and b3.numel() == 128
     assert hyper.dtype == F32 and hyper.is_contiguous() and tuple(hyper.shape) == (n, 32)
     assert ln_g.dtype == F32 and ln_b.dtype == F32 and ln_g.numel() == 64 and ln_b.numel() == 64
     low = torch.empty((n, 4 * g, 4 * g), device=u0.device, dtype=F32)
-    check(_lib.lib().ink_sam_upscale_tail(u0.data_ptr(), n, g, ln_g.data_ptr(), ln_b.data_ptr(), eps, blob.data_ptr(),
+    check(_lib.lib().ink_sam_upscale_tail(u0.data_ptr(), u0.stride(0), n, g, ln_g.data_ptr(), ln_b.data_ptr(), eps, blob.data_ptr(),
                                           b3.data_ptr(), hyper.data_ptr(), low.data_ptr(), _stream()), "ink_sam_upscale_tail")
     return low
 

@@ -298,6 +298,10 @@ class SamEngine:
         u = "mask_decoder.output_upscaling."
         w["up0.ws"] = ops.split_weight(m(u + "0.weight").permute(2, 3, 1, 0).reshape(4 * (E // 4), E))
         w["up3.ws"] = ops.split_weight(m(u + "3.weight").permute(2, 3, 1, 0).reshape(4 * (E // 8), E // 4))
+        # the final token->image k / v projections and the first transposed convolution read the same split operand of
+        # the final keys: ONE GEMM [k | v | up0] (N = 128 + 128 + 256)
+        w["dfin.kvu.ws"] = torch.cat([w["dfin.kv.ws"], w["up0.ws"]]).contiguous()
+        w["dfin.kvu.b"] = torch.cat([w["dfin.kv.b"], w["up0.b"]]).contiguous()
         if self.fuse_upscale_tail and tuple(w["up3.ws"].shape) == (128, 192):
             w["up3.blob"] = ops.sam_upscale_pack(w["up3.ws"].contiguous())          # csrc/upscale_tail.hip
         for j in range(3):
@@ -700,7 +704,8 @@ class SamEngine:
                 keys_next = None if last else y
                 ks = ops.layernorm_rows(y, w[d + ".norm4.w"], w[d + ".norm4.b"], 1e-5, split=True, split_f32=keys_next)
             keys = keys_next
-        kv = ops.gemm(ks, w["dfin.kv.ws"], w["dfin.kv.b"])
+        kvu = ops.gemm(ks, w["dfin.kvu.ws"], w["dfin.kvu.b"])                     # [n*T, k 128 | v 128 | up0 4*64]
+        kv = kvu[:, :2 * Eh]
         queries = ops.layernorm_rows(t2i_attend("dfin", queries, kv[:, :Eh], kv[:, Eh:], w["dfin.k_pe"], queries),
                                      w["dfin.norm.w"], w["dfin.norm.b"], 1e-5, out_dtype=F32)
         hs = queries.view(n, NT, E)
@@ -712,14 +717,15 @@ class SamEngine:
 
         hyper = mlp3("hyp", hs[:, 1].contiguous())          # mask token 0 -> [n, 32]
         iou = mlp3("iou", hs[:, 0].contiguous())[:, :1]     # iou token -> [n, 4] -> mask 0
-        u0 = lin(ks, "up0")                                                      # [n*T, 4*64]
+        u0 = kvu[:, 2 * Eh:]                                                     # [n*T, 4*64], row stride 512
         if "up3.blob" in w and (T * 4) % 32 == 0:
             # LayerNorm2d + GELU + the second transposed convolution + GELU + the hyper-network product in one kernel
             # (csrc/upscale_tail.hip): u0 is read once, 4 floats per row are written
-            low = ops.sam_upscale_tail(u0.view(n * T * 4, E // 4), n, g, w["up1.w"], w["up1.b"], 1e-6, w["up3.blob"],
-                                       w["up3.b"], hyper.contiguous())
+            low = ops.sam_upscale_tail(u0, n, g, w["up1.w"], w["up1.b"], 1e-6, w["up3.blob"], w["up3.b"],
+                                       hyper.contiguous())
         else:
-            u1 = ops.layernorm_rows(u0.view(n * T * 4, E // 4), w["up1.w"], w["up1.b"], 1e-6, act="gelu", split=True)
+            u1 = ops.layernorm_rows(u0.contiguous().view(n * T * 4, E // 4), w["up1.w"], w["up1.b"], 1e-6, act="gelu",
+                                    split=True)
             u2 = lin(u1, "up3", act="gelu")                                          # [n*T*4, 4*32]
             low = ops.sam_mask_logits(u2, hyper.contiguous(), n, g)                   # [n, 256, 256]
         return low, iou
