@@ -446,10 +446,11 @@ __global__ __launch_bounds__(256) void attn_fewkeys_kernel(const T* __restrict__
 // per (query, head), 4 of the 16 dimensions each, so that every load and store instruction of a wave covers one
 // contiguous KiB (a thread per (query, head) reads 64 B at a 64-B stride: every cache line is touched by four
 // instructions); the four partial dot products meet through two shuffles.  Base-2 softmax (log2 e folded into the scale).
+template <int NK>
 __global__ __launch_bounds__(256) void attn_fewkeys16_f32_kernel(const float* __restrict__ Q, int64_t ldq,
                                                                  const float* __restrict__ K, int64_t ldk,
                                                                  const float* __restrict__ V, int64_t ldv, int B,
-                                                                 int n_q, int n_k, int n_heads, float scale,
+                                                                 int n_q, int n_heads, float scale,
                                                                  const int32_t* __restrict__ q_rows,
                                                                  const float* __restrict__ q_add,
                                                                  float* __restrict__ O, int64_t ldo) {
@@ -463,31 +464,32 @@ __global__ __launch_bounds__(256) void attn_fewkeys16_f32_kernel(const float* __
   f32x4 qv = *(const f32x4*)(Q + (q_rows ? (int64_t)q_rows[b] + q : bq) * ldq + col);
   if (q_add) qv += *(const f32x4*)(q_add + (int64_t)q * n_heads * 16 + col);
   qv *= scale * 1.44269504088896340736f;
-  float sc[16];                                            // n_k <= 16; uniform guards keep the indices compile-time
-  float mx = -3.0e38f;
-  const float* kp = K + (int64_t)b * n_k * ldk + col;
+  const float* kp = K + (int64_t)b * NK * ldk + col;
+  const float* vp = V + (int64_t)b * NK * ldv + col;
+  f32x4 kv[NK], vv[NK];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    sc[t] = -3.0e38f;
-    if (t < n_k) {
-      const f32x4 kv = *(const f32x4*)(kp + (int64_t)t * ldk);
-      float d = (qv[0] * kv[0] + qv[1] * kv[1]) + (qv[2] * kv[2] + qv[3] * kv[3]);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      sc[t] = d;
-      mx = fmaxf(mx, d);
-    }
+  for (int t = 0; t < NK; ++t) {
+    kv[t] = *(const f32x4*)(kp + (int64_t)t * ldk);
+    vv[t] = *(const f32x4*)(vp + (int64_t)t * ldv);
+  }
+  float sc[NK];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < NK; ++t) {
+    float d = (qv[0] * kv[t][0] + qv[1] * kv[t][1]) + (qv[2] * kv[t][2] + qv[3] * kv[t][3]);
+    // the four lanes of a (query, head) group are a DPP quad: xor 1 = quad_perm [1,0,3,2], xor 2 = [2,3,0,1] (no LDS trip)
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, false));
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, false));
+    sc[t] = d;
+    mx = fmaxf(mx, d);
   }
   float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
-    if (t < n_k) { sc[t] = __builtin_amdgcn_exp2f(sc[t] - mx); sum += sc[t]; }
+  for (int t = 0; t < NK; ++t) { sc[t] = __builtin_amdgcn_exp2f(sc[t] - mx); sum += sc[t]; }
   const float inv = 1.f / sum;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const float* vp = V + (int64_t)b * n_k * ldv + col;
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
-    if (t < n_k) acc += (sc[t] * inv) * *(const f32x4*)(vp + (int64_t)t * ldv);
+  for (int t = 0; t < NK; ++t) acc += (sc[t] * inv) * vv[t];
   *(f32x4*)(O + bq * ldo + col) = acc;
 }
 
@@ -966,10 +968,10 @@ extern "C" int ink_attn_fewkeys(const void* Q, int64_t ldq, const void* K, int64
   else if (head_dim == 64 && !io_f32) INK_FEWKEYS(64, f16);
   else if (head_dim == 16 && !io_f32) INK_FEWKEYS(16, f16);
   else if (head_dim == 32) INK_FEWKEYS(32, float);
-  else if (head_dim == 16 && !blocked && n_k <= 16) {
+  else if (head_dim == 16 && !blocked && n_k == 7) {        // SAM's 5 output tokens + 2 box corners
     const int64_t t4 = total * 4;
-    hipLaunchKernelGGL(attn_fewkeys16_f32_kernel, dim3((unsigned)((t4 + 255) / 256)), block, 0, s, (const float*)Q, ldq,
-                       (const float*)K, ldk, (const float*)V, ldv, B, n_q, n_k, n_heads, scale, q_batch_rows, q_add,
+    hipLaunchKernelGGL(attn_fewkeys16_f32_kernel<7>, dim3((unsigned)((t4 + 255) / 256)), block, 0, s, (const float*)Q, ldq,
+                       (const float*)K, ldk, (const float*)V, ldv, B, n_q, n_heads, scale, q_batch_rows, q_add,
                        (float*)O, ldo);
   } else if (head_dim == 16) INK_FEWKEYS(16, float);
   else return INK_ERR_ARG;
