@@ -324,12 +324,15 @@ int ink_biattn_colstats(const float* scores, int32_t B, int32_t S, int32_t HT, f
  * q / value_v projections (256 -> 2 x 1024) or the 1024 -> 256 image output projection - see csrc/fusion_fold.hip for
  * the algebra.  text_k / text_vl: f32 [B*T, >= 1024] (row stride ld_text) = l_proj / values_l_proj of LN_l(l);
  * Wq / Wvv f16 [1024, 256] (v_proj / values_v_proj weights), bq / bvv f32 [1024]; Wo f16 [256, 1024], bo f32 [256]
- * (out_v_proj); scale = 256^-0.5.  ws: f32[ink_fusion_fold_workspace(B, S)].  S <= 32768. */
+ * (out_v_proj); scale = 256^-0.5.  ws: f32[ink_fusion_fold_workspace(B, S)].  S <= 32768.  Optional (NULL to skip): out16 f16
+ * [B*S, 256] = f16(updated v) and out16_pos = f16(updated v + pos[s]) with pos f32 [S, 256] - the operands of the
+ * deformable attention's value / sampling projections (transformer.py:780-789), written in the same pass. */
 int ink_fusion_fold_workspace(int32_t B, int32_t S, int64_t* out_floats);
 int ink_fusion_fold(float* v_f32, int32_t B, int32_t S, const float* lnv_g, const float* lnv_b, float eps,
                     const float* text_k_f32, const float* text_vl_f32, int64_t ld_text, int32_t T, const void* Wq_f16,
                     const float* bq, const void* Wvv_f16, const float* bvv, const void* Wo_f16, const float* bo,
-                    const float* gamma_v, float scale, float* ws, void* out_l_f16, void* stream);
+                    const float* gamma_v, float scale, float* ws, void* out_l_f16, const float* pos, void* out16_pos,
+                    void* out16, void* stream);
 
 /* Tail of the SAM mask decoder in one kernel (csrc/upscale_tail.hip): LayerNorm2d + GELU + the second ConvTranspose2d
  * (k2 s2 = a [64 -> 4 x 32] projection per row) + GELU + the hyper-network product of mask token 0

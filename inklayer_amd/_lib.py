@@ -88,7 +88,8 @@ SIGNATURES = {
     "ink_ffn256_fused": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
                          c_void_p, c_void_p],
     "ink_fusion_fold": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_i64, c_int, c_void_p,
-                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p],
+                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                        c_void_p, c_void_p, c_void_p],
     "ink_attn_fewkeys": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int,
                          c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p],
     "ink_attn_fewq": [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int,

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void fuse_apply_kernel(float* __restrict__ x, 
                                                          const float* __restrict__ scores,
                                                          const float* __restrict__ stats, const float* __restrict__ Z,
                                                          const float* __restrict__ gamma, const float* __restrict__ bo,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, const float* __restrict__ pos,
+                                                         f16* __restrict__ out16_pos, f16* __restrict__ out16) {
   __shared__ __attribute__((aligned(16))) float red[FJ * FD];
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 z[FJ];
@@ -178,7 +179,15 @@ __global__ __launch_bounds__(256) void fuse_apply_kernel(float* __restrict__ x, 
       o += p * z[q];
       acc[q] += w * v;
     }
-    *(f32x4*)row = v + gv * o;
+    const f32x4 nv = v + gv * o;
+    *(f32x4*)row = nv;
+    // the f16 operands of the deformable attention's two projections (query = x + pos, value = x), written here instead
+    // of by two add_cvt passes over the tokens
+    if (out16) *(f16x4*)(out16 + ((int64_t)b * S + s) * FD + lane * 4) = (f16x4){(f16)nv[0], (f16)nv[1], (f16)nv[2], (f16)nv[3]};
+    if (out16_pos) {
+      const f32x4 pv4 = nv + *(const f32x4*)(pos + (int64_t)s * FD + lane * 4);
+      *(f16x4*)(out16_pos + ((int64_t)b * S + s) * FD + lane * 4) = (f16x4){(f16)pv4[0], (f16)pv4[1], (f16)pv4[2], (f16)pv4[3]};
+    }
   }
   // the four waves' accumulators -> one partial per workgroup
   for (int wv = 0; wv < 4; ++wv) {
@@ -246,10 +255,11 @@ extern "C" int ink_fusion_fold(float* v_f32, int32_t B, int32_t S, const float* 
                                const float* text_k_f32, const float* text_vl_f32, int64_t ld_text, int32_t T,
                                const void* Wq_f16, const float* bq, const void* Wvv_f16, const float* bvv,
                                const void* Wo_f16, const float* bo, const float* gamma_v, float scale, float* ws,
-                               void* out_l_f16, void* stream) {
+                               void* out_l_f16, const float* pos, void* out16_pos, void* out16, void* stream) {
   INK_CHECK_ARG(v_f32 && lnv_g && lnv_b && text_k_f32 && text_vl_f32 && Wq_f16 && bq && Wvv_f16 && bvv && Wo_f16 && bo &&
                 gamma_v && ws && out_l_f16);
   INK_CHECK_ARG(B > 0 && S > 0 && S <= 64 * 512 && T >= 1 && T <= 4 && ld_text >= FH * FHD);
+  INK_CHECK_ARG(!out16_pos || pos);
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (S + 127) / 128;
   float* U = ws;
@@ -265,7 +275,7 @@ extern "C" int ink_fusion_fold(float* v_f32, int32_t B, int32_t S, const float* 
                      lnv_b, eps, (const float*)U, (const float*)c, scores);
   if (ink_biattn_colstats(scores, B, S, FJ, cpart, stats, stream) != INK_OK) return INK_ERR_LAUNCH;
   hipLaunchKernelGGL(fuse_apply_kernel, dim3(nchunk, B), dim3(256), 0, s, v_f32, S, 128, (const float*)scores,
-                     (const float*)stats, (const float*)Z, gamma_v, bo, partial);
+                     (const float*)stats, (const float*)Z, gamma_v, bo, partial, pos, (f16*)out16_pos, (f16*)out16);
   hipLaunchKernelGGL(fuse_text_kernel, dim3(FJ, B), dim3(1024), 0, s, (const float*)partial, nchunk, (const float*)stats,
                      (const f16*)Wvv_f16, bvv, T, (f16*)out_l_f16);
   return ink_launch_status();

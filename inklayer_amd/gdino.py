@@ -480,8 +480,10 @@ class GDinoEngine:
         cfg, w, dev, T, S = self.cfg, self.w, self.dev, self.T, pl.S
         text = self.text0.repeat(B, 1)                        # [B*T, 256] (plumbing copy)
         s16 = torch.empty((B * S, 256), device=dev, dtype=F16)
+        s16p = torch.empty((B * S, 256), device=dev, dtype=F16)
         for i in range(cfg.enc_layers):
             d = f"e{i}"
+            have16 = False
             # --- BiAttentionBlock (fuse_modules.py:286-295): residual from the NORMALISED v / l
             ln32 = torch.empty_like(text)
             l16 = torch.empty(text.shape, device=dev, dtype=F16)
@@ -490,9 +492,11 @@ class GDinoEngine:
                 # the caption's <= 4 tokens folded through the fusion layer (csrc/fusion_fold.hip): no per-token
                 # 256 -> 2048 projection, no 1024 -> 256 image output projection, f32 throughout
                 kl = ops.gemm(l16, w[d + ".fu.kl.w"], w[d + ".fu.kl.b"])
+                # ... and the f16 operands of this layer's deformable attention (x + pos, x) leave in the same pass
                 ol = ops.fusion_fold(src, B, S, w[d + ".fu.lnv.w"], w[d + ".fu.lnv.b"], 1e-5, kl, T, w[d + ".fu.qv.w"],
                                      w[d + ".fu.qv.b"], w[d + ".fu.outv.w"], w[d + ".fu.outv.b"], w[d + ".fu.gv"],
-                                     256 ** -0.5)
+                                     256 ** -0.5, pos=pl.pos, out16_pos=s16p, out16=s16)
+                have16 = True
             else:
                 vn = torch.empty_like(src)
                 ops.layernorm_rows(src, w[d + ".fu.lnv.w"], w[d + ".fu.lnv.b"], 1e-5, out=vn, out2=s16)
@@ -512,8 +516,12 @@ class GDinoEngine:
             text = ops.layernorm_rows(ops.gemm(ff, w[d + ".txt.lin2.w"], w[d + ".txt.lin2.b"], residual=text),
                                       w[d + ".txt.norm2.w"], w[d + ".txt.norm2.b"], 1e-5, out_dtype=F32)
             # --- DeformableTransformerEncoderLayer (transformer.py:780-799)
-            proj = ops.gemm(ops.add_cvt_f16(src, pl.pos, out=s16), w[d + ".msda.proj.w"], w[d + ".msda.proj.b"])
-            val = ops.gemm(ops.add_cvt_f16(src, out=s16), w[d + ".msda.value.w"], w[d + ".msda.value.b"], out_dtype=F16)
+            if have16:
+                proj = ops.gemm(s16p, w[d + ".msda.proj.w"], w[d + ".msda.proj.b"])
+                val = ops.gemm(s16, w[d + ".msda.value.w"], w[d + ".msda.value.b"], out_dtype=F16)
+            else:
+                proj = ops.gemm(ops.add_cvt_f16(src, pl.pos, out=s16), w[d + ".msda.proj.w"], w[d + ".msda.proj.b"])
+                val = ops.gemm(ops.add_cvt_f16(src, out=s16), w[d + ".msda.value.w"], w[d + ".msda.value.b"], out_dtype=F16)
             o = ops.msda_fused(val, proj, pl.enc_ref, pl.shapes, B, S, ref_batched=False)
             y = ops.gemm(o, w[d + ".msda.out.w"], w[d + ".msda.out.b"], residual=src, out=src)
             ops.layernorm_rows(y, w[d + ".norm1.w"], w[d + ".norm1.b"], 1e-5, out=src, out2=s16)

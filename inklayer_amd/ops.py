@@ -556,10 +556,15 @@ def biattn_fusion(qv16: torch.Tensor, kl16: torch.Tensor, B: int, S: int, T: int
 
 def fusion_fold(v: torch.Tensor, B: int, S: int, lnv_g: torch.Tensor, lnv_b: torch.Tensor, eps: float,
                 text_kv: torch.Tensor, T: int, Wqv: torch.Tensor, bqv: torch.Tensor, Wo: torch.Tensor, bo: torch.Tensor,
-                gamma_v: torch.Tensor, scale: float) -> torch.Tensor:
+                gamma_v: torch.Tensor, scale: float, pos: Optional[torch.Tensor] = None,
+                out16_pos: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None) -> torch.Tensor:
     """BiAttentionBlock with the <= 4 caption tokens folded through it (csrc/fusion_fold.hip): v f32 [B*S, 256] is
     updated IN PLACE; returns the text-side attention output f16 [B*T, 1024].  text_kv: f32 [B*T, 2048] =
-    [l_proj | values_l_proj] of LN_l(l); Wqv f16 [2048, 256] / bqv f32 [2048] = [v_proj ; values_v_proj]."""
+    [l_proj | values_l_proj] of LN_l(l); Wqv f16 [2048, 256] / bqv f32 [2048] = [v_proj ; values_v_proj].  out16 /
+    out16_pos (f16 [B*S, 256], optional): f16(v) and f16(v + pos[s]) of the UPDATED v, pos f32 [S, 256]."""
+    for t in (out16, out16_pos):
+        assert t is None or (t.dtype == F16 and t.is_contiguous() and tuple(t.shape) == (B * S, 256))
+    assert out16_pos is None or (pos is not None and pos.dtype == F32 and pos.is_contiguous() and tuple(pos.shape) == (S, 256))
     assert v.dtype == F32 and v.is_contiguous() and tuple(v.shape) == (B * S, 256)
     assert text_kv.dtype == F32 and text_kv.stride(1) == 1 and tuple(text_kv.shape) == (B * T, 2048)
     assert Wqv.dtype == F16 and Wqv.is_contiguous() and tuple(Wqv.shape) == (2048, 256) and bqv.dtype == F32
@@ -571,7 +576,8 @@ def fusion_fold(v: torch.Tensor, B: int, S: int, lnv_g: torch.Tensor, lnv_b: tor
     check(_lib.lib().ink_fusion_fold(v.data_ptr(), B, S, lnv_g.data_ptr(), lnv_b.data_ptr(), eps, text_kv.data_ptr(),
                                      text_kv[:, 1024:].data_ptr(), text_kv.stride(0), T, Wqv.data_ptr(), bqv.data_ptr(),
                                      Wqv[1024:].data_ptr(), bqv[1024:].data_ptr(), Wo.data_ptr(), bo.data_ptr(),
-                                     gamma_v.data_ptr(), scale, ws.data_ptr(), out_l.data_ptr(), _stream()),
+                                     gamma_v.data_ptr(), scale, ws.data_ptr(), out_l.data_ptr(), _p(pos), _p(out16_pos),
+                                     _p(out16), _stream()),
           "ink_fusion_fold")
     return out_l
 
