@@ -353,10 +353,17 @@ int ink_sam_upscale_tail(const float* u0, int64_t ld_tok, int32_t n, int32_t g, 
  * f16 [hid, 256], linear1.bias f32 [hid] (carried as an f16 hi + lo pair in a 17th k-step, i.e. to 2^-22) and
  * linear2.weight f16 [256, hid]: per 64 hidden units the LDS image the kernel streams - 1-KiB MFMA operand blocks,
  * linear2's columns permuted inside 16-blocks to the order phase A leaves them in registers.  b2: linear2.bias. */
-int ink_ffn256_pack_bytes(int32_t hid, int64_t* out_bytes);
-int ink_ffn256_pack(const void* w1_f16, const float* b1, const void* w2_f16, int32_t hid, void* blob, void* stream);
+int ink_ffn256_pack_bytes(int32_t hid, int32_t with_pre, int64_t* out_bytes);
+int ink_ffn256_pack(const void* w1_f16, const float* b1, const void* w2_f16, int32_t hid, const void* wpre_f16, void* blob,
+                    void* stream);
 int ink_ffn256_fused(const void* x_f16, int64_t ldx, const float* res_f32, const void* blob, const float* b2,
-                     const float* ln_g, const float* ln_b, float eps, int32_t M, int32_t hid, float* out_f32, void* stream);
+                     const float* ln_g, const float* ln_b, float eps, int32_t M, int32_t hid, const float* pre_bias,
+                     const float* pre_ln_g, const float* pre_ln_b, float* out_f32, void* stream);
+/* With a PRECEDING projection (wpre_f16 f16 [256, 256] given to the pack, pre_bias / pre_ln_g / pre_ln_b f32 [256] to the
+ * call; all NULL = the plain form above): x is the input of that projection and the kernel computes
+ *     s = LayerNorm_pre(res + x wpre^T + pre_bias);   out = LayerNorm(s + linear2(relu(linear1(f16(s)))))
+ * = the deformable attention's output projection + residual + norm1 + the feed-forward block + norm2 of
+ * DeformableTransformerEncoderLayer.forward (transformer.py:780-799) in one launch; s never leaves the registers. */
 
 /* Two-stage query selection (transformer.py:293-300): indices of the K largest max_t logits[b,s,t],
  * descending, ties -> lower index.  logits f32 [B,S,T]; out_idx int32 [B,K].  S <= 16384 is one LDS

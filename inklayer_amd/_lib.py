@@ -83,10 +83,10 @@ SIGNATURES = {
     "ink_sam_upscale_pack": [c_void_p, c_void_p, c_void_p],
     "ink_sam_upscale_tail": [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p],
-    "ink_ffn256_pack_bytes": [c_int, C.POINTER(c_i64)],
-    "ink_ffn256_pack": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "ink_ffn256_pack_bytes": [c_int, c_int, C.POINTER(c_i64)],
+    "ink_ffn256_pack": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "ink_ffn256_fused": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
-                         c_void_p, c_void_p],
+                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ink_fusion_fold": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_i64, c_int, c_void_p,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                         c_void_p, c_void_p, c_void_p],

@@ -215,6 +215,7 @@ def clean_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 class GDinoEngine:
     fuse_ffn = True          # encoder FFN + norm2 as one kernel (csrc/ffn_fused.hip); False: two GEMMs + LayerNorm
+    fuse_ffn_pre = True      # ... starting at the deformable attention's output projection (out_proj + norm1 inside)
     fold_fusion = True       # the caption's tokens folded through the fusion layers (csrc/fusion_fold.hip); False: rounds 1-2 path
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[GDinoConfig] = None,
@@ -310,6 +311,9 @@ class GDinoEngine:
             ln(d + ".norm1", p + "norm1"); lin(d + ".lin1", p + "linear1"); lin(d + ".lin2", p + "linear2"); ln(d + ".norm2", p + "norm2")
             if w[d + ".lin1.w"].shape[1] == 256 and w[d + ".lin1.w"].shape[0] % 64 == 0 and w[d + ".lin1.w"].shape[0] <= 2048:
                 w[d + ".ffn.blob"] = ops.ffn256_pack(w[d + ".lin1.w"], w[d + ".lin1.b"], w[d + ".lin2.w"])     # csrc/ffn_fused.hip
+                # ... and the form that starts at the deformable attention's output projection (out_proj + norm1 inside)
+                w[d + ".ffn.blob_pre"] = ops.ffn256_pack(w[d + ".lin1.w"], w[d + ".lin1.b"], w[d + ".lin2.w"],
+                                                         w[d + ".msda.out.w"])
             p = f"{t}encoder.text_layers.{i}."
             mha(d + ".txt", p + "self_attn.")
             lin(d + ".txt.lin1", p + "linear1"); lin(d + ".txt.lin2", p + "linear2")
@@ -523,6 +527,13 @@ class GDinoEngine:
                 proj = ops.gemm(ops.add_cvt_f16(src, pl.pos, out=s16), w[d + ".msda.proj.w"], w[d + ".msda.proj.b"])
                 val = ops.gemm(ops.add_cvt_f16(src, out=s16), w[d + ".msda.value.w"], w[d + ".msda.value.b"], out_dtype=F16)
             o = ops.msda_fused(val, proj, pl.enc_ref, pl.shapes, B, S, ref_batched=False)
+            if self.fuse_ffn and self.fuse_ffn_pre and (d + ".ffn.blob_pre") in w:
+                # out_proj + residual + norm1 + linear1 + relu + linear2 + residual + norm2: one kernel, `src` read and
+                # written once
+                ops.ffn256_fused(o, src, w[d + ".ffn.blob_pre"], int(w[d + ".lin1.b"].numel()), w[d + ".lin2.b"],
+                                 w[d + ".norm2.w"], w[d + ".norm2.b"], 1e-5, out=src,
+                                 pre=(w[d + ".msda.out.b"], w[d + ".norm1.w"], w[d + ".norm1.b"]))
+                continue
             y = ops.gemm(o, w[d + ".msda.out.w"], w[d + ".msda.out.b"], residual=src, out=src)
             ops.layernorm_rows(y, w[d + ".norm1.w"], w[d + ".norm1.b"], 1e-5, out=src, out2=s16)
             if self.fuse_ffn and (d + ".ffn.blob") in w:

@@ -608,39 +608,45 @@ def sam_upscale_tail(u0: torch.Tensor, n: int, g: int, ln_g: torch.Tensor, ln_b:
     return low
 
 
-def ffn256_pack(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
-    """linear1.weight f16 [hid, 256] + linear1.bias f32 [hid] + linear2.weight f16 [256, hid] -> the packed weight blob of
-    ffn256_fused (done once at load time; csrc/ffn_fused.hip)."""
+def ffn256_pack(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, w_pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """linear1.weight f16 [hid, 256] + linear1.bias f32 [hid] + linear2.weight f16 [256, hid] (+ the weight f16 [256, 256] of
+    a preceding projection, see ffn256_fused) -> the packed weight blob (done once at load time; csrc/ffn_fused.hip)."""
     hid = int(w1.shape[0])
     assert w1.dtype == F16 and w2.dtype == F16 and w1.is_contiguous() and w2.is_contiguous()
     assert tuple(w1.shape) == (hid, 256) and tuple(w2.shape) == (256, hid)
     assert b1.dtype == F32 and b1.is_contiguous() and b1.numel() == hid
+    assert w_pre is None or (w_pre.dtype == F16 and w_pre.is_contiguous() and tuple(w_pre.shape) == (256, 256))
     need = C.c_int64(0)
-    check(_lib.lib().ink_ffn256_pack_bytes(hid, C.byref(need)), "ink_ffn256_pack_bytes")
+    check(_lib.lib().ink_ffn256_pack_bytes(hid, int(w_pre is not None), C.byref(need)), "ink_ffn256_pack_bytes")
     blob = torch.empty(need.value // 2, device=w1.device, dtype=F16)
-    check(_lib.lib().ink_ffn256_pack(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), hid, blob.data_ptr(), _stream()),
+    check(_lib.lib().ink_ffn256_pack(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), hid, _p(w_pre), blob.data_ptr(), _stream()),
           "ink_ffn256_pack")
     return blob
 
 
 def ffn256_fused(x16: torch.Tensor, res: torch.Tensor, blob: torch.Tensor, hid: int, b2: torch.Tensor,
-                 ln_g: torch.Tensor, ln_b: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 ln_g: torch.Tensor, ln_b: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None,
+                 pre: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
     """LayerNorm(res + linear2(relu(linear1(x16)))) for d_model 256 in one kernel (transformer.py:780-799).  x16 f16
     [M, 256] (row stride free), res f32 [M, 256]; blob = ffn256_pack(...) of a d_ffn = hid layer; out f32 [M, 256] (may be
-    `res`)."""
+    `res`).  pre = (bias, ln_weight, ln_bias) of a preceding projection whose weight is in the blob: then
+    s = LayerNorm_pre(res + x16 W_pre^T + bias) is formed first and the block runs on s (x16 = that projection's input)."""
     M = int(x16.shape[0])
     assert x16.dtype == F16 and x16.stride(1) == 1 and x16.shape[1] == 256
     assert res.dtype == F32 and res.is_contiguous() and tuple(res.shape) == (M, 256)
     need = C.c_int64(0)
-    check(_lib.lib().ink_ffn256_pack_bytes(hid, C.byref(need)), "ink_ffn256_pack_bytes")
+    check(_lib.lib().ink_ffn256_pack_bytes(hid, int(pre is not None), C.byref(need)), "ink_ffn256_pack_bytes")
     assert blob.dtype == F16 and blob.numel() * 2 == need.value and b2.dtype == F32
     assert b2.numel() == 256 and ln_g.numel() == 256 and ln_b.numel() == 256 and ln_g.dtype == F32 and ln_b.dtype == F32
+    if pre is not None:
+        assert all(t.dtype == F32 and t.is_contiguous() and t.numel() == 256 for t in pre)
     if out is None:
         out = torch.empty_like(res)
     assert out.dtype == F32 and out.is_contiguous() and tuple(out.shape) == (M, 256)
+    pb, pg, pe = pre if pre is not None else (None, None, None)
     check(_lib.lib().ink_ffn256_fused(x16.data_ptr(), x16.stride(0), res.data_ptr(), blob.data_ptr(), b2.data_ptr(),
-                                      ln_g.data_ptr(), ln_b.data_ptr(), eps, M, hid, out.data_ptr(), _stream()),
-          "ink_ffn256_fused")
+                                      ln_g.data_ptr(), ln_b.data_ptr(), eps, M, hid, _p(pb), _p(pg), _p(pe), out.data_ptr(),
+                                      _stream()), "ink_ffn256_fused")
     return out
 
 

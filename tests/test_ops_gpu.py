@@ -454,3 +454,40 @@ def test_fused_ffn_equals_the_two_projection_form(dev, M, hid):
     # in place: out aliases res
     got2 = ops.ffn256_fused(d(x16), xs, blob, hid, d(b2), d(lg), d(lb), 1e-5, out=xs)
     assert got2.data_ptr() == xs.data_ptr() and torch.equal(got2, got)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("M", [1000, 13294 + 5])
+def test_fused_ffn_with_the_preceding_projection(dev, M):
+    """ops.ffn256_fused(pre=...): s = LN1(res + x Wpre^T + b), out = LN2(s + linear2(relu(linear1(f16(s))))) - the tail
+    of DeformableTransformerEncoderLayer.forward (transformer.py:780-799) from the attention's output projection on -
+    against float64 with the same rounding points and against the three-launch form (GEMM + LayerNorm + fused FFN)."""
+    from inklayer_amd import ops
+    hid = 2048
+    g = torch.Generator().manual_seed(M)
+    x16 = (torch.randn(M, 256, generator=g) * 0.8).half()
+    res = torch.randn(M, 256, generator=g) * 1.5 + 0.3
+    wp = (torch.randn(256, 256, generator=g) / 16).half()
+    w1 = (torch.randn(hid, 256, generator=g) / 16).half()
+    w2 = (torch.randn(256, hid, generator=g) / 45).half()
+    bp, b1, b2 = torch.randn(256, generator=g) * 0.2, torch.randn(hid, generator=g) * 0.2, torch.randn(256, generator=g) * 0.2
+    g1, e1 = 1 + 0.1 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g)
+    g2, e2 = 1 + 0.1 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g)
+    ln = torch.nn.functional.layer_norm
+    s_ = ln(res.double() + x16.double() @ wp.double().T + bp.double(), (256,), g1.double(), e1.double(), 1e-5)
+    s16 = s_.float().half()
+    h = torch.relu(s16.double() @ w1.double().T + b1.double()).float().half()
+    want = ln(s_ + h.double() @ w2.double().T + b2.double(), (256,), g2.double(), e2.double(), 1e-5)
+    d = lambda t: t.to(dev).contiguous()
+    blob = ops.ffn256_pack(d(w1), d(b1), d(w2), d(wp))
+    got = ops.ffn256_fused(d(x16), d(res), blob, hid, d(b2), d(g2), d(e2), 1e-5, pre=(d(bp), d(g1), d(e1)))
+    ea = (got.double().cpu() - want).abs()
+    print(f"M={M}: out_proj + norm1 + FFN + norm2 fused vs float64 max abs {ea.max().item():.2e}, mean abs {ea.mean().item():.2e}")
+    assert torch.isfinite(got).all() and ea.max().item() < 2e-3 and ea.mean().item() < 1e-5
+    y = ops.gemm(d(x16), d(wp), d(bp), residual=d(res))
+    sx = torch.empty_like(y)
+    s16d = torch.empty(y.shape, device=dev, dtype=torch.float16)
+    ops.layernorm_rows(y, d(g1), d(e1), 1e-5, out=sx, out2=s16d)
+    three = ops.ffn256_fused(s16d, sx, ops.ffn256_pack(d(w1), d(b1), d(w2)), hid, d(b2), d(g2), d(e2), 1e-5)
+    e3 = (got - three).abs()
+    assert e3.max().item() < 2e-3 and e3.mean().item() < 1e-5
