@@ -344,6 +344,18 @@ int ink_sam_upscale_pack(const void* ws_f16, void* blob_f16, void* stream);
 int ink_sam_upscale_tail(const float* u0, int64_t ld_tok, int32_t n, int32_t g, const float* ln_g, const float* ln_b, float eps,
                          const void* blob_f16, const float* b3, const float* hyper, float* low, void* stream);
 
+/* Image-side tail of a layer of SAM's two-way transformer in one kernel (csrc/proj_ln.hip):
+ *     out = LayerNorm(res + a W^T + bias)         a f32 [rows, 128] (the image->token attention's output), 256 columns
+ * = cross_attn_image_to_token.out_proj + the residual + norm4 (SA/modeling/transformer.py:175-182).  The projection runs
+ * on split-f16 operands (built in registers from a; blob = the weight as the split-f16 matrix [256, 384] packed by
+ * ink_proj256_ln_pack, 192 KiB).  res f32 [.., 256]: row r, or - res_batch_rows given - row res_batch_rows[r /
+ * rows_per_batch] + r % rows_per_batch of a tensor shared by the boxes of an image.  Outputs (either may be NULL): out_f32
+ * [rows, 256] and out_split_f16 [rows, 768], the split-f16 operand [hi | lo*64 | hi/64] of the next projection. */
+int ink_proj256_ln_pack(const void* ws_f16, void* blob_f16, void* stream);
+int ink_proj256_ln(const float* a_f32, const void* blob_f16, const float* bias, const float* res_f32,
+                   const int32_t* res_batch_rows, int32_t rows_per_batch, const float* ln_g, const float* ln_b, float eps,
+                   int64_t rows, float* out_f32, void* out_split_f16, void* stream);
+
 /* Feed-forward block of the deformable encoder layer, fused (csrc/ffn_fused.hip):
  *     out = LayerNorm(res + linear2(relu(linear1(x))))      d_model 256, d_ffn = hid (multiple of 64, <= 2048)
  * = DeformableTransformerEncoderLayer.forward_ffn + norm2 (GD/models/GroundingDINO/transformer.py:780-799).  x f16 [M, 256]

@@ -80,6 +80,9 @@ SIGNATURES = {
                           c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "ink_biattn_colstats": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ink_fusion_fold_workspace": [c_int, c_int, C.POINTER(c_i64)],
+    "ink_proj256_ln_pack": [c_void_p, c_void_p, c_void_p],
+    "ink_proj256_ln": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_i64, c_void_p,
+                       c_void_p, c_void_p],
     "ink_sam_upscale_pack": [c_void_p, c_void_p, c_void_p],
     "ink_sam_upscale_tail": [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p],

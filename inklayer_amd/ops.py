@@ -582,6 +582,38 @@ def fusion_fold(v: torch.Tensor, B: int, S: int, lnv_g: torch.Tensor, lnv_b: tor
     return out_l
 
 
+def proj256_ln_pack(ws: torch.Tensor) -> torch.Tensor:
+    """A [128 -> 256] projection as the split-f16 matrix [256, 384] -> the LDS image of proj256_ln (load time)."""
+    assert ws.dtype == F16 and ws.is_contiguous() and tuple(ws.shape) == (256, 384)
+    blob = torch.empty(3 * 64 * 64 * 8, device=ws.device, dtype=F16)
+    check(_lib.lib().ink_proj256_ln_pack(ws.data_ptr(), blob.data_ptr(), _stream()), "ink_proj256_ln_pack")
+    return blob
+
+
+def proj256_ln(a: torch.Tensor, blob: torch.Tensor, bias: torch.Tensor, res: torch.Tensor, ln_g: torch.Tensor,
+               ln_b: torch.Tensor, eps: float, *, res_batch_rows: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
+               want_f32: bool = True, want_split: bool = True):
+    """LayerNorm(res + a W^T + bias) in one kernel (transformer.py:175-182: out_proj + residual + norm4 of the image
+    tokens; csrc/proj_ln.hip).  a f32 [R, 128]; res f32 [R, 256] or, with res_batch_rows (int32 per box), a tensor shared
+    by the boxes of an image.  -> (f32 [R, 256] or None, split-f16 operand [R, 768] or None)."""
+    R = int(a.shape[0])
+    assert a.dtype == F32 and a.is_contiguous() and tuple(a.shape) == (R, 128)
+    assert blob.dtype == F16 and blob.numel() == 3 * 64 * 64 * 8
+    assert res.dtype == F32 and res.is_contiguous() and res.shape[1] == 256
+    assert all(t.dtype == F32 and t.is_contiguous() and t.numel() == 256 for t in (bias, ln_g, ln_b))
+    if res_batch_rows is not None:
+        assert res_batch_rows.dtype == torch.int32 and res_batch_rows.is_cuda and rows_per_batch > 0
+        assert res_batch_rows.numel() * rows_per_batch == R
+    else:
+        assert res.shape[0] == R
+    of = torch.empty((R, 256), device=a.device, dtype=F32) if want_f32 else None
+    osp = torch.empty((R, 768), device=a.device, dtype=F16) if want_split else None
+    check(_lib.lib().ink_proj256_ln(a.data_ptr(), blob.data_ptr(), bias.data_ptr(), res.data_ptr(), _p(res_batch_rows),
+                                    rows_per_batch, ln_g.data_ptr(), ln_b.data_ptr(), eps, R, _p(of), _p(osp), _stream()),
+          "ink_proj256_ln")
+    return of, osp
+
+
 def sam_upscale_pack(ws: torch.Tensor) -> torch.Tensor:
     """output_upscaling.3 as the split-f16 matrix [128, 192] -> the LDS image of sam_upscale_tail (load time)."""
     assert ws.dtype == F16 and ws.is_contiguous() and tuple(ws.shape) == (128, 192)

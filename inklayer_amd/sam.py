@@ -302,6 +302,9 @@ class SamEngine:
         # the final keys: ONE GEMM [k | v | up0] (N = 128 + 128 + 256)
         w["dfin.kvu.ws"] = torch.cat([w["dfin.kv.ws"], w["up0.ws"]]).contiguous()
         w["dfin.kvu.b"] = torch.cat([w["dfin.kv.b"], w["up0.b"]]).contiguous()
+        if self.fuse_proj_ln and E == 256:
+            for i in range(cfg.dec_depth):
+                w[f"d{i}.i2t.out_proj.blob"] = ops.proj256_ln_pack(w[f"d{i}.i2t.out_proj.ws"].contiguous())   # csrc/proj_ln.hip
         if self.fuse_upscale_tail and tuple(w["up3.ws"].shape) == (128, 192):
             w["up3.blob"] = ops.sam_upscale_pack(w["up3.ws"].contiguous())          # csrc/upscale_tail.hip
         for j in range(3):
@@ -376,6 +379,7 @@ class SamEngine:
     # size is captured the second time it is seen (a capture costs three forwards and pins a private pool for the
     # neck's intermediates); the result is cloned out of that pool.
     graph_blocks = False
+    fuse_proj_ln = True          # image-side out_proj + residual + norm4 (+ split operand) as one kernel (csrc/proj_ln.hip)
     fuse_upscale_tail = True     # LayerNorm2d + GELU + ConvT + GELU + hyper product as one kernel (csrc/upscale_tail.hip)
     graph_cache_size = 2
 
@@ -691,6 +695,13 @@ class SamEngine:
             # norm4 writes the next consumer's split operand in the same pass (the keys feed only projections from here
             # on); the f32 copy is kept only while a later layer still adds to it
             last = i + 1 == cfg.dec_depth
+            if self.fuse_proj_ln and (d + ".i2t.out_proj.blob") in w:
+                # out_proj + residual + norm4 (+ the split operand) in one kernel (csrc/proj_ln.hip)
+                keys, ks = ops.proj256_ln(a, w[d + ".i2t.out_proj.blob"], w[d + ".i2t.out_proj.b"], keys, w[d + ".norm4.w"],
+                                          w[d + ".norm4.b"], 1e-5, res_batch_rows=img_rows if shared else None,
+                                          rows_per_batch=T if shared else 0, want_f32=not last, want_split=True)
+                shared = False
+                continue
             if shared:
                 # keys are still one copy per IMAGE: the residual add happens inside the LayerNorm through a per-box
                 # row gather - no per-box copy of the image keys (repeat_interleave of mask_decoder.py:124) is made

@@ -295,3 +295,44 @@ def test_upscale_tail_kernel_equals_the_three_kernel_form(dev, n, g):
     err3 = ((low - three).abs().max() / three.abs().max()).item()
     print(f"n={n} g={g}: fused tail vs float64 max-rel {err:.2e}, vs the three-kernel form {err3:.2e}")
     assert err < 5e-6 and err3 < 5e-6
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("shared", [False, True])
+def test_proj_layernorm_kernel_equals_the_three_kernel_form(dev, shared):
+    """ops.proj256_ln (csrc/proj_ln.hip) = LayerNorm(res + a W^T + b) with the projection on split-f16 operands, f32 and
+    split outputs (transformer.py:175-182 on the per-box image tokens) against float64 and against add_split + GEMM +
+    layernorm_rows; `shared`: the residual is a per-image tensor gathered per box."""
+    from inklayer_amd import ops
+    gen = torch.Generator().manual_seed(7 + int(shared))
+    n, T = 3, 200                                     # 600 rows: a ragged last tile
+    R = n * T
+    a = torch.randn(R, 128, generator=gen) * 0.8
+    w = torch.randn(256, 128, generator=gen) / 11
+    b = torch.randn(256, generator=gen) * 0.2
+    lg, lb = 1 + 0.1 * torch.randn(256, generator=gen), 0.1 * torch.randn(256, generator=gen)
+    if shared:
+        keys = torch.randn(2 * T, 256, generator=gen)                       # two images, boxes 0, 1 -> image 0, box 2 -> image 1
+        rows = torch.tensor([0, 0, T], dtype=torch.int32)
+        res = torch.cat([keys[0:T], keys[0:T], keys[T:2 * T]], 0)
+    else:
+        keys, rows, res = torch.randn(R, 256, generator=gen), None, None
+        res = keys
+    want = torch.nn.functional.layer_norm(res.double() + a.double() @ w.double().t() + b.double(), (256,), lg.double(),
+                                          lb.double(), 1e-5)
+    d = lambda t: t.to(dev).contiguous()
+    ws = ops.split_weight(d(w))
+    of, osp = ops.proj256_ln(d(a), ops.proj256_ln_pack(ws), d(b), d(keys), d(lg), d(lb), 1e-5,
+                             res_batch_rows=d(rows) if shared else None, rows_per_batch=T if shared else 0)
+    err = ((of.double().cpu() - want).abs().max() / want.abs().max()).item()
+    hi, lo = osp[:, :256].float(), osp[:, 256:512].float() / 64.0
+    rec = ((hi + lo).double().cpu() - want).abs().max().item()
+    assert torch.equal(osp[:, 512:], (osp[:, :256].float() / 64.0).half())
+    y = ops.gemm(ops.add_split_f16(d(a)), ws, d(b), residual=d(res))
+    three = ops.layernorm_rows(y, d(lg), d(lb), 1e-5, out_dtype=torch.float32)
+    e3 = ((of - three).abs().max() / three.abs().max()).item()
+    print(f"shared={shared}: fused vs float64 max-rel {err:.2e}, split reconstruction max abs {rec:.2e}, vs three kernels {e3:.2e}")
+    assert err < 3e-6 and e3 < 3e-6 and rec < 2e-5
+    only_split = ops.proj256_ln(d(a), ops.proj256_ln_pack(ws), d(b), d(keys), d(lg), d(lb), 1e-5,
+                                res_batch_rows=d(rows) if shared else None, rows_per_batch=T if shared else 0, want_f32=False)
+    assert only_split[0] is None and torch.equal(only_split[1], osp)
