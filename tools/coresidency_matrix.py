@@ -56,8 +56,30 @@ def main():
     blob = ops.ffn256_pack(w1, bb1, w2)
     xs16 = x256.half()
     A2, W2 = rn(106352, 256).half(), (rn(2048, 256) / 16).half()
+    # round-3 kernels of the SAM decoder / detector encoder
+    n_box, T = 32, 4096
+    a_att = rn(n_box * T, 128)
+    keys_r = rn(n_box * T, 256)
+    pl_blob = ops.proj256_ln_pack(ops.split_weight(rn(256, 128) / 11))
+    u0 = rn(n_box * T, 256)
+    up_blob = ops.sam_upscale_pack(ops.split_weight(rn(128, 64) / 8))
+    hyper = rn(n_box, 32)
+    b3 = rn(128)
+    g64, b64 = rn(64), rn(64)
+    q7 = rn(n_box * 7, 128)
+    kv = rn(n_box * T, 256)
+    qi = rn(n_box * T, 128)
+    k7, v7 = rn(n_box * 7, 128), rn(n_box * 7, 128)
+    blob_pre = ops.ffn256_pack(w1, bb1, w2, (rn(256, 256) / 16).half())
     aggressors = {
         "nothing": (lambda: None, 0),
+        "proj256_ln": (lambda: ops.proj256_ln(a_att, pl_blob, b256, keys_r, g256, b256, 1e-5), 4),
+        "upscale_tail": (lambda: ops.sam_upscale_tail(u0, n_box, 64, g64, b64, 1e-6, up_blob, b3, hyper), 4),
+        "attn_fewq16 (2 wave groups)": (lambda: ops.attn_fewq(q7, kv[:, :128], kv[:, 128:], n_batch=n_box, n_heads=8, head_dim=16,
+                                                             scale=0.25, n_q=7, n_k=T), 8),
+        "attn_fewkeys16": (lambda: ops.attn_fewkeys(qi, k7, v7, B=n_box, n_heads=8, head_dim=16, scale=0.25, n_q=T), 8),
+        "ffn256 fused with pre-phase": (lambda: ops.ffn256_fused(xs16, x256, blob_pre, 2048, bb2, g256, b256, 1e-5,
+                                                                 pre=(b256, g256, b256)), 5),
         "win4 window attention": (lambda: ops.flash_attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], n_q=S * S, n_k=S * S, rel_aug=aug,
                                                          grid_w=S, tok_rows=wm, pad_k=pad_k, pad_v=pad_v, out=out, **kw), 12),
         "glob4 global attention": (lambda: ops.flash_attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], rel_h=rh, rel_w=rw, grid_w=gr,
