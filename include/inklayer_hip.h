@@ -158,14 +158,18 @@ typedef struct InkAttn {
   int32_t grid_w;
   const int32_t* q_batch_rows;
   const int32_t* kv_batch_rows;
-  const float* rel_h; const float* rel_w;         /* mode 1 */
+  const float* rel_h; const float* rel_w;         /* mode 1 (f16 tables when rel_f16 != 0: ink_relpos_bias64_f16) */
   const void* rel_aug;                            /* mode 2 */
   const float* dense_bias; const float* dense_mask; /* mode 3 */
-  int32_t n_mask; int32_t _pad;
+  int32_t n_mask; int32_t rel_f16;                /* rel_f16: 0 / 1, SAM's own shape only (was padding: 0 in older callers) */
   const int32_t* tok_rows;                        /* mode 2, optional */
   const void* pad_k; const void* pad_v;           /* f16 rows used for tok_rows == -1 keys */
 } InkAttn;
 int ink_flash_attn(const InkAttn* p, void* stream);
+
+/* ink_relpos_bias for the 64 x 64 grid with f16 output tables [n_batch*n_heads*4096, 64] (InkAttn.rel_f16 = 1). */
+int ink_relpos_bias64_f16(const void* Q, int64_t ldq, const float* rel_pos_h, const float* rel_pos_w, int32_t n_batch,
+                          int32_t n_heads, int32_t head_dim, float scale, void* out_h_f16, void* out_w_f16, void* stream);
 
 /* Decomposed relative-position terms of SA/modeling/image_encoder.py:292-361
  * (get_rel_pos + the two einsums of add_decomposed_rel_pos), divided by `scale`:

@@ -36,7 +36,7 @@ class InkAttn(C.Structure):
         ("head_dim", c_int), ("scale", c_float), ("bias_mode", c_int), ("grid_w", c_int),
         ("q_batch_rows", c_void_p), ("kv_batch_rows", c_void_p),
         ("rel_h", c_void_p), ("rel_w", c_void_p), ("rel_aug", c_void_p),
-        ("dense_bias", c_void_p), ("dense_mask", c_void_p), ("n_mask", c_int), ("_pad", c_int),
+        ("dense_bias", c_void_p), ("dense_mask", c_void_p), ("n_mask", c_int), ("rel_f16", c_int),
         ("tok_rows", c_void_p), ("pad_k", c_void_p), ("pad_v", c_void_p),
     ]
 
@@ -80,6 +80,7 @@ SIGNATURES = {
                           c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "ink_biattn_colstats": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ink_fusion_fold_workspace": [c_int, c_int, C.POINTER(c_i64)],
+    "ink_relpos_bias64_f16": [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "ink_proj256_ln_pack": [c_void_p, c_void_p, c_void_p],
     "ink_proj256_ln": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_i64, c_void_p,
                        c_void_p, c_void_p],

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_kernel(InkAttn p) {
 // Tab = [rel_pos_h (2S-1 rows, padded to RT*32) ; rel_pos_w (same)], then a scattered store
 // out[q][j] = D[q_x - j + S - 1][q].  One workgroup per (batch*head, block of QB*32 queries); the table is
 // converted to f16 once into LDS (A operand via ds_read_b128), Q^T fragments come straight from HBM.
-template <int HD, int S, bool AUG>
+template <int HD, int S, bool AUG, bool F16T = false>
 __global__ __launch_bounds__(256) void relpos_mfma_kernel(const f16* __restrict__ Q, int64_t ldq,
                                                           const float* __restrict__ Rh,
                                                           const float* __restrict__ Rw, int n_heads,
@@ -582,10 +582,22 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const f16* __restrict_
       }
       if (!AUG && (tt % RT) == RT - 1) {
         // one table done for these 32 queries: rows of 64 f32 -> lane (q, hh) stores its 128-B half row
-        float* dst = (is_w ? out_w : out_h) + ((int64_t)bh * NQ + q) * S + hh * 32;
-        if (q_ok) {
+        if (F16T) {
+          // f16 tables (out_h / out_w carry f16 pointers): half the bytes written here and read by the attention kernel
+          f16* dst = (f16*)(is_w ? out_w : out_h) + ((int64_t)bh * NQ + q) * S + hh * 32;
+          if (q_ok) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) *(f32x4*)(dst + 4 * i) = *(const f32x4*)(ot + lq * OROW + hh * 128 + i * 16);
+            for (int i = 0; i < 4; ++i) {
+              const f32x4 a = *(const f32x4*)(ot + lq * OROW + hh * 128 + i * 32), c = *(const f32x4*)(ot + lq * OROW + hh * 128 + i * 32 + 16);
+              *(f16x8*)(dst + 8 * i) = (f16x8){(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)c[0], (f16)c[1], (f16)c[2], (f16)c[3]};
+            }
+          }
+        } else {
+          float* dst = (is_w ? out_w : out_h) + ((int64_t)bh * NQ + q) * S + hh * 32;
+          if (q_ok) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(f32x4*)(dst + 4 * i) = *(const f32x4*)(ot + lq * OROW + hh * 128 + i * 16);
+          }
         }
       }
     }
@@ -633,6 +645,7 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
     INK_CHECK_ARG(p.rel_h && p.rel_w && p.grid_w == 64 && p.n_k % 64 == 0);
     // SAM's own shape (64 x 64 tokens): the one-wave-per-SIMD kernel of attention_glob.hip
     if (p.n_q % 256 == 0 && p.n_k % 128 == 0 && p.n_k >= 256 && p.n_k <= 4096) return ink_glob4_attn_launch(p, s);
+    INK_CHECK_ARG(!p.rel_f16);          // f16 tables: the one-wave-per-SIMD kernel only
     INK_FA(80, 1, 8);
   } else if (p.head_dim == 80 && p.bias_mode == 2) {
     INK_CHECK_ARG(p.rel_aug && p.grid_w > 0 && p.grid_w <= 16 && p.n_k <= p.grid_w * p.grid_w && p.n_k <= 256);
@@ -662,6 +675,17 @@ extern "C" int ink_flash_attn(const InkAttn* pp, void* stream) {
   }
 #undef INK_FA
 #undef INK_FA_X
+  return ink_launch_status();
+}
+
+extern "C" int ink_relpos_bias64_f16(const void* Q, int64_t ldq, const float* rel_pos_h, const float* rel_pos_w,
+                                     int32_t n_batch, int32_t n_heads, int32_t head_dim, float scale, void* out_h_f16,
+                                     void* out_w_f16, void* stream) {
+  INK_CHECK_ARG(Q && rel_pos_h && rel_pos_w && head_dim == 80 && ldq % 8 == 0 && out_h_f16 && out_w_f16);
+  INK_CHECK_ARG(n_batch > 0 && n_heads > 0 && scale > 0.f && ((((uintptr_t)out_h_f16 | (uintptr_t)out_w_f16) & 15) == 0));
+  hipLaunchKernelGGL((relpos_mfma_kernel<80, 64, false, true>), dim3(n_batch * n_heads * 16), dim3(256), 0, (hipStream_t)stream,
+                     (const f16*)Q, ldq, rel_pos_h, rel_pos_w, n_heads, 1.0f / scale, (const int32_t*)nullptr,
+                     (float*)out_h_f16, (float*)out_w_f16, (f16*)nullptr);
   return ink_launch_status();
 }
 

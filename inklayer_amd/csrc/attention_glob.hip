@@ -189,7 +189,11 @@ __device__ __forceinline__ void sm_first(int g, Sub& u, float c, float rh) {
 }
 __device__ __forceinline__ void sm_second(int g, Sub& u, float c) { sm_exp(8 + g, u, c); }
 
+// RF16: rel_h / rel_w are f16 tables (ink_relpos_bias64_f16): converted when rel_w enters the LDS table / when the tile's
+// rel_h scalar is fetched - half the table bytes written and read per launch
+template <bool RF16>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void glob4_attn_kernel(InkAttn p) {
+  using RT = std::conditional_t<RF16, f16, float>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // claims the SIMD's whole register file like the window kernel (attention_win.hip: waves of other kernels sharing a
   // SIMD with that kernel read corrupted registers; this one, same structure, showed nothing in tools/coresidency_matrix.py
@@ -220,15 +224,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   load_q(B, qlB);
   // rel_w rows of the tile's 256 queries -> LDS
   {
-    const float* RW = p.rel_w + ((int64_t)bh * p.n_q + (int64_t)qb * 256) * 64;
+    const RT* RW = (const RT*)p.rel_w + ((int64_t)bh * p.n_q + (int64_t)qb * 256) * 64;
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int ci = it * NT + tid, q = ci >> 4, c4 = ci & 15;
-      *(f32x4*)(sRW + q * RWROW + c4 * 16) = *(const f32x4*)(RW + q * 64 + c4 * 4);
+      if constexpr (RF16) {
+        const f16x4 v = *(const f16x4*)(RW + q * 64 + c4 * 4);
+        *(f32x4*)(sRW + q * RWROW + c4 * 16) = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+      } else {
+        *(f32x4*)(sRW + q * RWROW + c4 * 16) = *(const f32x4*)(RW + q * 64 + c4 * 4);
+      }
     }
   }
-  const float* RHA = p.rel_h + ((int64_t)bh * p.n_q + (int64_t)qb * 256 + qlA) * 64;
-  const float* RHB = p.rel_h + ((int64_t)bh * p.n_q + (int64_t)qb * 256 + qlB) * 64;
+  const RT* RHA = (const RT*)p.rel_h + ((int64_t)bh * p.n_q + (int64_t)qb * 256 + qlA) * 64;
+  const RT* RHB = (const RT*)p.rel_h + ((int64_t)bh * p.n_q + (int64_t)qb * 256 + qlB) * 64;
   // V pad columns of both tile buffers (ones at d = 80 / 84, then zeros), written once
   for (int i = tid; i < 2 * 64 * 2; i += NT) {
     const int buf = i >> 7, row = (i >> 1) & 63, pc = i & 1;
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int r = 0; r < 4; ++r) { u.s0[4 * g + r] = a[r]; u.s1[4 * g + r] = c2[r]; }
   };
-  float rhA = RHA[0], rhB = RHB[0];             // rel_h of tile 0
+  float rhA = (float)RHA[0], rhB = (float)RHB[0];             // rel_h of tile 0
 #pragma unroll
   for (int g = 0; g < 4; ++g) { read_rw(A, qlA, g); read_rw(B, qlB, g); }
 #pragma unroll
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       pv_mfma(g, vf, A);
       sm_first<FIRST>(g, B, c, rhB);
       if constexpr (g < NQK) read_k(1 - PAR, g);
-      if constexpr (g == 5) { rhA1 = RHA[(t + 1) & 63]; rhB1 = RHB[(t + 1) & 63]; }
+      if constexpr (g == 5) { rhA1 = (float)RHA[(t + 1) & 63]; rhB1 = (float)RHB[(t + 1) & 63]; }
       if constexpr (g >= 6 && g % 2 == 0) l_write(PAR, ic<PAR>{}, ic<(g - 6) / 2>{});
       if constexpr (g >= 8) read_rw(A, qlA, g - 8);               // (A's scores of tile t are consumed: unit 2)
       GAP();
@@ -442,11 +451,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 // Launcher used by ink_flash_attn (attention.hip) for bias_mode 1.
 __attribute__((visibility("hidden"))) int ink_glob4_attn_launch(const InkAttn& p, hipStream_t s) {
-  static bool attr = ((void)hipFuncSetAttribute((const void*)glob4_attn_kernel,
+  static bool attr = ((void)hipFuncSetAttribute((const void*)glob4_attn_kernel<false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES),
+                      (void)hipFuncSetAttribute((const void*)glob4_attn_kernel<true>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), true);
   (void)attr;
   const int grid = p.n_batch * p.n_heads * (p.n_q >> 8);
-  hipLaunchKernelGGL(glob4_attn_kernel, dim3(grid), dim3(NT), LDS_BYTES, s, p);
+  if (p.rel_f16) {
+    hipLaunchKernelGGL(glob4_attn_kernel<true>, dim3(grid), dim3(NT), LDS_BYTES, s, p);
+  } else {
+    hipLaunchKernelGGL(glob4_attn_kernel<false>, dim3(grid), dim3(NT), LDS_BYTES, s, p);
+  }
   return ink_launch_status();
 }
 

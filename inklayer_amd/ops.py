@@ -327,9 +327,10 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: in
         if tok_rows is not None:
             p.tok_rows, p.pad_k, p.pad_v = tok_rows.data_ptr(), pad_k.data_ptr(), pad_v.data_ptr()
     elif rel_h is not None:
-        assert rel_h.dtype == F32 and rel_w.dtype == F32
+        assert rel_h.dtype == rel_w.dtype and rel_h.dtype in (F32, F16)      # f16 tables: relpos_bias(..., f16_tables=True)
         assert rel_h.is_contiguous() and rel_w.is_contiguous()
         p.bias_mode, p.rel_h, p.rel_w = 1, rel_h.data_ptr(), rel_w.data_ptr()
+        p.rel_f16 = int(rel_h.dtype == F16)
     else:
         p.bias_mode = 0
     if _ATTN_TRACE is None:
@@ -345,14 +346,23 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, n_batch: in
 
 def relpos_bias(q: torch.Tensor, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tensor, *, S: int,
                 n_batch: int, n_heads: int, head_dim: int, scale: float, out=None,
-                tok_rows: Optional[torch.Tensor] = None):
-    """SAM decomposed rel-pos terms / scale.  S == 64 -> (rel_h, rel_w) f32; S <= 16 -> rel_aug f16."""
+                tok_rows: Optional[torch.Tensor] = None, f16_tables: bool = False):
+    """SAM decomposed rel-pos terms / scale.  S == 64 -> (rel_h, rel_w) f32 (f16 with f16_tables: SAM's own attention shape
+    only); S <= 16 -> rel_aug f16."""
     assert q.dtype == F16 and q.stride(1) == 1
     assert rel_pos_h.dtype == F32 and rel_pos_h.is_contiguous()
     assert rel_pos_w.dtype == F32 and rel_pos_w.is_contiguous()
     assert rel_pos_h.shape == (2 * S - 1, head_dim)
     n = n_batch * n_heads * S * S
     fn = _lib.lib().ink_relpos_bias
+    if S == 64 and f16_tables:
+        oh, ow = out if out is not None else (torch.empty((n, 64), device=q.device, dtype=F16),
+                                              torch.empty((n, 64), device=q.device, dtype=F16))
+        assert oh.dtype == F16 and ow.dtype == F16 and oh.numel() >= n * 64 and ow.numel() >= n * 64
+        check(_lib.lib().ink_relpos_bias64_f16(q.data_ptr(), q.stride(0), rel_pos_h.data_ptr(), rel_pos_w.data_ptr(), n_batch,
+                                               n_heads, head_dim, scale, oh.data_ptr(), ow.data_ptr(), _stream()),
+              "ink_relpos_bias64_f16")
+        return oh, ow
     if S == 64:
         oh, ow = out if out is not None else (torch.empty((n, 64), device=q.device, dtype=F32),
                                               torch.empty((n, 64), device=q.device, dtype=F32))

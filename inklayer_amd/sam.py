@@ -346,8 +346,11 @@ class SamEngine:
         self.hid = e(B * T, int(D * cfg.mlp_ratio))
         H = cfg.num_heads
         self.rel_aug = e(B * nwin * nwin * H * ws * ws, 32)
-        self.rel_h = e(B * H * T, 64, dt=F32)
-        self.rel_w = e(B * H * T, 64, dt=F32)
+        # decomposed rel-pos terms of the global blocks: f16 tables at SAM's own grid (the one-wave-per-SIMD kernel converts
+        # them on the way into LDS / the exponent: half the bytes written by relpos_bias and read back), f32 otherwise
+        rdt = F16 if (self.rel_f16_tables and cfg.grid == 64) else F32
+        self.rel_h = e(B * H * T, 64, dt=rdt)
+        self.rel_w = e(B * H * T, 64, dt=rdt)
 
     # ------------------------------------------------------------------ encoder
     def encode(self, images_u8: Sequence[torch.Tensor], chan_reverse: bool = False,
@@ -382,6 +385,7 @@ class SamEngine:
     # size is captured the second time it is seen (a capture costs three forwards and pins a private pool for the
     # neck's intermediates); the result is cloned out of that pool.
     graph_blocks = False
+    rel_f16_tables = True        # global attention's rel-pos tables in f16 (grid 64 only)
     fuse_proj_ln = True          # image-side out_proj + residual + norm4 (+ split operand) as one kernel (csrc/proj_ln.hip)
     fuse_upscale_tail = True     # LayerNorm2d + GELU + ConvT + GELU + hyper product as one kernel (csrc/upscale_tail.hip)
     graph_cache_size = 2
@@ -455,7 +459,7 @@ class SamEngine:
             if i in cfg.global_attn_indexes:
                 rh, rw = ops.relpos_bias(q, w[k + "attn.rel_pos_h"], w[k + "attn.rel_pos_w"], S=cfg.grid,
                                          n_batch=B, n_heads=H, head_dim=80, scale=self.scale,
-                                         out=(self.rel_h, self.rel_w))
+                                         out=(self.rel_h, self.rel_w), f16_tables=self.rel_h.dtype == F16)
                 o = ops.flash_attn(q, kk, v, n_batch=B, n_heads=H, head_dim=80, scale=self.scale,
                                    rel_h=rh, rel_w=rw, grid_w=cfg.grid, out=self.att[:B * T])
             else:

@@ -198,6 +198,15 @@ def test_flash_attn_sam(dev, S, B, H, relpos):
     err = (out.double() - ref).abs().max().item()
     assert torch.isfinite(out).all()
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
+    if relpos and S == 64:
+        # the same with f16 rel-pos tables (round 3: what the engine uses at SAM's own grid)
+        r16 = ops.relpos_bias(q, rph, rpw, S=S, n_batch=B, n_heads=H, head_dim=hd, scale=scale, f16_tables=True)
+        assert r16[0].dtype == torch.float16
+        assert (r16[0].float() - r[0]).abs().max().item() <= 2 ** -10 * r[0].abs().max().item()
+        out16 = ops.flash_attn(q, k, v, n_batch=B, n_heads=H, head_dim=hd, scale=scale, rel_h=r16[0], rel_w=r16[1], grid_w=64)
+        err16 = (out16.double() - ref).abs().max().item()
+        print(f"global attention vs float64: f32 tables {err:.2e}, f16 tables {err16:.2e}")
+        assert torch.isfinite(out16).all() and err16 < 4e-3 * max(1.0, ref.abs().max().item()), err16
 
 
 @pytest.mark.parametrize("plant", [(70,), (150,), (194,), (70, 150, 194), (3, 194)])
