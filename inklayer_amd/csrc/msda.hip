@@ -71,6 +71,36 @@ __device__ __forceinline__ void sample_acc(const VT* __restrict__ vbase, int64_t
   }
 }
 
+// One sample for the fused kernel, branch-free: every corner is loaded from a clamped (always valid) address and an
+// out-of-range corner / sample gets weight 0, so that the four gathers of the sample are in flight together (the
+// conditional form above waits for each corner's load inside its own branch).  fma(0, v, acc) == acc for the finite f16
+// values of the map and the accumulation order is unchanged.  (All 16 gathers of a LEVEL in flight was tried: 64 more
+// registers halve the occupancy - 290 -> 370 us.)
+__device__ __forceinline__ void sample_acc_bf(const f16* __restrict__ vbase, int64_t row_stride, int H, int W, float h_im,
+                                              float w_im, float aw, float (&acc)[8]) {
+  const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const int h0 = in ? (int)hf : 0, w0 = in ? (int)wf : 0;
+  const float lh = h_im - hf, lw = w_im - wf;
+  const float hh = 1.f - lh, hw = 1.f - lw;
+  const bool t = h0 >= 0, b = h0 + 1 <= H - 1, l = w0 >= 0, r = w0 + 1 <= W - 1;
+  const float w00 = (in && t && l) ? hh * hw * aw : 0.f, w01 = (in && t && r) ? hh * lw * aw : 0.f;
+  const float w10 = (in && b && l) ? lh * hw * aw : 0.f, w11 = (in && b && r) ? lh * lw * aw : 0.f;
+  const int ht = max(h0, 0), hb = min(h0 + 1, H - 1), wl = max(w0, 0), wr = min(w0 + 1, W - 1);
+  const f16x8 v00 = *(const f16x8*)(vbase + ((int64_t)ht * W + wl) * row_stride);
+  const f16x8 v01 = *(const f16x8*)(vbase + ((int64_t)ht * W + wr) * row_stride);
+  const f16x8 v10 = *(const f16x8*)(vbase + ((int64_t)hb * W + wl) * row_stride);
+  const f16x8 v11 = *(const f16x8*)(vbase + ((int64_t)hb * W + wr) * row_stride);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = fmaf(w00, (float)v00[i], acc[i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = fmaf(w01, (float)v01[i], acc[i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = fmaf(w10, (float)v10[i], acc[i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = fmaf(w11, (float)v11[i], acc[i]);
+}
+
 // ---- reference-ABI form: explicit locations + weights, f32 value, C == 32
 __global__ __launch_bounds__(256) void msda_ref_kernel(const float* __restrict__ value,
                                                        const float* __restrict__ loc,
@@ -164,7 +194,7 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const f16* __restrict__
         lx = rx + ox / (float)P * rw * 0.5f;
         ly = ry + oy / (float)P * rh * 0.5f;
       }
-      sample_acc<f16>(vb, rs, H, W, ly * H - 0.5f, lx * W - 0.5f, lg[l * P + p] * inv, acc);
+      sample_acc_bf(vb, rs, H, W, ly * H - 0.5f, lx * W - 0.5f, lg[l * P + p] * inv, acc);
     }
   }
   f16x8 o;
