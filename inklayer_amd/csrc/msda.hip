@@ -74,8 +74,8 @@ __device__ __forceinline__ void sample_acc(const VT* __restrict__ vbase, int64_t
 // One sample for the fused kernel, branch-free: every corner is loaded from a clamped (always valid) address and an
 // out-of-range corner / sample gets weight 0, so that the four gathers of the sample are in flight together (the
 // conditional form above waits for each corner's load inside its own branch).  fma(0, v, acc) == acc for the finite f16
-// values of the map and the accumulation order is unchanged.  (All 16 gathers of a LEVEL in flight was tried: 64 more
-// registers halve the occupancy - 290 -> 370 us.)
+// values of the map and the accumulation order is unchanged.  (Two samples / all 16 gathers of a level in flight were tried:
+// 16 / 48 more registers cost occupancy - 245 -> 394 / 370 us.)
 __device__ __forceinline__ void sample_acc_bf(const f16* __restrict__ vbase, int64_t row_stride, int H, int W, float h_im,
                                               float w_im, float aw, float (&acc)[8]) {
   const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
