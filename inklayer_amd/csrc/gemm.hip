@@ -506,6 +506,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_nt(InkGemm p, int group
 // 1 = folded LayerNorm -> f16 (qkv), 2 = folded LayerNorm + GELU -> f16 (lin1), 3 = split residual in, split C + row
 // statistics out (proj, lin2).  Separate kernels rather than more branches: with every form inside one kernel the
 // register allocator spilled around the dispatch.
+// EPI == 4 of the ping-pong kernel: an asm global load with a scalar base and a 32-bit lane offset (asm: hipcc turns
+// its own vmcnt waits into vmcnt(0) while an LDS-DMA is in flight; the loop's counted waits cover this load, see there)
+__device__ __forceinline__ void rmf_global_load(f32x4& dst, const float* base, uint32_t byte_off) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_pp(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_pp<I + 1, N>(f);
+  }
+}
+
 template <int RING, int TN, int ABL = 0, bool LATE_A = (TN > 4), int EPI = 0>
 __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   constexpr int BM = 256, BN = 64 * TN, BK = 32, NT = 512;
@@ -608,11 +621,21 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   for (int g = 0; g < AHEAD; ++g) dma(g, g);
   if (EPI == 1 || EPI == 2) ln_rows_prologue<TM, TN>(p, strip, m0 + grp * 128, n0 + wn * WNC, lane);   // (drains the fill, like a preload)
   f32x4 acc[TM][TN];
-  init_wave_tile<TM, TN, EPI == 3>(acc, p, rows, n0 + wn * WNC, lane);
-  if (residual_preloaded(p) || EPI == 1 || EPI == 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
+  if constexpr (EPI == 4) {
+    // the f32 residual enters THROUGH THE MFMA PIPE during the K loop (below) instead of being preloaded into the
+    // accumulators: nothing to wait for here but granule 0
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[ti][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     wait_ahead(std::integral_constant<int, AHEAD - 1>{});
+  } else {
+    init_wave_tile<TM, TN, EPI == 3>(acc, p, rows, n0 + wn * WNC, lane);
+    if (residual_preloaded(p) || EPI == 1 || EPI == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      wait_ahead(std::integral_constant<int, AHEAD - 1>{});
+    }
   }
   slot_end();
   if (grp == 1) slot_end();                         // the stagger: group 1 idles through slot 0
@@ -623,7 +646,7 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   const int co = (fq ^ Swz<BK>::f(fr)) << 4;        // one k-step of 32 per granule: logical chunk = fq
   f16x8 a[AG], w[TN];
   int cslot = 0, islot = AHEAD % RING;
-  for (int g = 0; g < G; ++g) {
+  auto iter = [&](int g) __attribute__((always_inline)) {
     const char* bA = smem + cslot * GRAN;
     const char* bW = bA + TILE_A;
     // ---- LOAD slot
@@ -663,9 +686,74 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
       for (int i = 0; i < AG; ++i) acc[i][0][0] += (float)a[i][0] + (float)w[i % TN][1];
     }
     __builtin_amdgcn_s_setprio(0);
+  };
+  auto iter_end = [&]() __attribute__((always_inline)) {
     slot_end();
     cslot = (cslot + 1 == RING) ? 0 : cslot + 1;
     islot = (islot + 1 == RING) ? 0 : islot + 1;
+  };
+  if constexpr (EPI != 4) {
+    for (int g = 0; g < G; ++g) {
+      iter(g);
+      iter_end();
+    }
+  } else {
+    // ---- residual through the MFMA pipe.  The 40 accumulator tiles (ti, j) of the wave take their residual block
+    // R[16 rows, 16 columns] as  acc += I16 . hi(R)^T + I16 . lo(R)^T  (two v_mfma_f32_16x16x16_f16 with a 16 x 16
+    // identity as the first operand; hi = f16(R), lo = f16(R - hi): R to 2^-22), one tile every G / 40 granules.  The
+    // lane's f32x4 of R (the address the preload read) is fetched one step earlier by an asm global load issued in
+    // the MFMA slot, i.e. AFTER that granule's LDS-DMA: it is older than the next granule's DMA pieces, so the loop's
+    // counted vmcnt waits - unchanged - also cover it.  (With the preload all 256 workgroups of a round read their
+    // 328-KB residual tiles at once, before any MFMA: 17 us per round, 34 of proj's 135-146 us.)  The K loop is split
+    // into TM static blocks so that the accumulator row ti is a compile-time index and only j is a 5-way branch.
+    typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+    f32x4 rraw = {0.f, 0.f, 0.f, 0.f};
+    f16x4v idv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) idv[e] = (fr == 4 * fq + e) ? (f16)1.0f : (f16)0.0f;
+    const int gpb = G / TM, rstride = gpb / TN;          // granules per block / per residual step
+    const uint32_t roff0 = (uint32_t)(n0 + wn * WNC + fq * 4) * 4u;
+    auto rmf_apply = [&](auto tti, auto jj) __attribute__((always_inline)) {
+      constexpr int ti = decltype(tti)::value, j = decltype(jj)::value;
+      f16x4v hi, lo;
+      asm volatile("" : "+v"(rraw));       // (stays behind the loop's vmcnt waits, like every volatile asm)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (f16)rraw[e];
+        lo[e] = (f16)(rraw[e] - (float)hi[e]);
+      }
+      if (rows[ti] < 0) { hi = (f16x4v){0, 0, 0, 0}; lo = hi; }
+      acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(idv, hi, acc[ti][j], 0, 0, 0);
+      acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(idv, lo, acc[ti][j], 0, 0, 0);
+    };
+    auto rmf_load = [&](auto tti, int j) __attribute__((always_inline)) {
+      constexpr int ti = decltype(tti)::value;
+      rmf_global_load(rraw, p.residual, (uint32_t)max(rows[ti], 0) * (uint32_t)p.ldr * 4u + roff0 + (uint32_t)j * 64u);
+    };
+    static_for_pp<0, TM>([&](auto tti) {
+      constexpr int ti = decltype(tti)::value;
+      for (int gi = 0; gi < gpb; ++gi) {
+        iter(ti * gpb + gi);
+        if (gi % rstride == 0) {
+          const int j = gi / rstride;          // 0 .. TN - 1: apply the block loaded one step ago, then load (ti, j)
+          if (j == 0) {
+            if constexpr (ti > 0) rmf_apply(std::integral_constant<int, (ti > 0 ? ti - 1 : 0)>{}, std::integral_constant<int, TN - 1>{});
+          } else if (j == 1) {
+            rmf_apply(tti, std::integral_constant<int, 0>{});
+          } else if (j == 2) {
+            rmf_apply(tti, std::integral_constant<int, 1>{});
+          } else if (j == 3) {
+            rmf_apply(tti, std::integral_constant<int, 2>{});
+          } else {
+            rmf_apply(tti, std::integral_constant<int, (TN > 4 ? 3 : 0)>{});
+          }
+          rmf_load(tti, j);
+        }
+        iter_end();
+      }
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the last residual block
+    rmf_apply(std::integral_constant<int, TM - 1>{}, std::integral_constant<int, TN - 1>{});
   }
   if (grp == 0) slot_end();                         // group 0 idles through the last slot (same barrier count)
   stamp_rt(2);
@@ -680,6 +768,8 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
     store_wave_tile<TM, TN, 1, INK_ACT_GELU, true>(acc, p, er, rows, n0 + wn * WNC, lane, strip);
   } else if constexpr (EPI == 3) {
     store_wave_tile<TM, TN, 2, INK_ACT_NONE>(acc, p, er, rows, n0 + wn * WNC, lane);
+  } else if constexpr (EPI == 4) {
+    store_wave_tile<TM, TN, 0, INK_ACT_NONE>(acc, p, er, rows, n0 + wn * WNC, lane);
   } else if (p.c_f16) {
     if (plain && p.act == INK_ACT_GELU) {          // lin1 of the ViT-H MLP
       store_wave_tile<TM, TN, 1, INK_ACT_GELU>(acc, p, er, rows, n0 + wn * WNC, lane);
@@ -712,6 +802,8 @@ template <int RING, int TN = 4, int ABL = 0, bool LATE_A = (TN > 4), int EPI = 0
 static int launch_gemm_pp(const InkGemm& p, hipStream_t s, int group_m) {
   if (p.K / 32 < RING) return 1;
   if (EPI == 0 && (p.ln_stats || p.c_f16 == 2 || p.res_hi)) return INK_ERR_ARG;
+  if (EPI == 4 && !(TN == 5 && p.residual && !p.c_f16 && p.act == INK_ACT_NONE && !p.col_scale && (p.K / 32) % 40 == 0 &&
+                    (int64_t)p.M * p.ldr * 4 < ((int64_t)1 << 32))) return INK_ERR_ARG;
   constexpr int BN = 64 * TN;
   constexpr int lds = RING * (256 + BN) * 32 * 2 + 8 * (128 + 16 * TN) * 8;   // ring + the LayerNorm-fold strips of the 8 waves
   static_assert(lds <= 160 * 1024, "LDS budget");
@@ -739,6 +831,7 @@ static int launch_gemm(const InkGemm& p, hipStream_t s, int group_m = 1) {
 }  // namespace
 
 static int g_variant = -1;
+constexpr bool RMF_DEFAULT = false;   // variant 54 (residual through the MFMA pipe) for the eligible in-place f32 projections
 // shape heuristic (tools/gemm_sweep.py on MI355X): the ping-pong 256x320 tile when N is a multiple of 320 and the
 // launch is at least ~1.5 rounds of 256 CUs (SAM ViT-H: N = 1280 / 3840 / 5120, where batch 8 gives exact round
 // counts and 10 % fewer staged bytes per flop than 256x256); else the 16-wave 256x256 tile whenever it fills the
@@ -763,7 +856,7 @@ extern "C" int ink_gemm_set_variant(int32_t v) {
   const int vv = v >= 10000 ? v - 10000 : v;
   const int base = vv >= 100 ? vv % 100 : vv;
   bool ok = base == -1 || base == 0 || base == 10 || base == 11 || base == 12 || base == 14 || base == 16 ||
-            base == 32 || base == 40 || base == 42 || base == 45 || base == 47 || base == 53;
+            base == 32 || base == 40 || base == 42 || base == 45 || base == 47 || base == 53 || base == 54;
 #ifdef INK_ABLATION
   ok = ok || (base >= 21 && base <= 23) || base == 43 || base == 44 || base == 46 || (base >= 48 && base <= 52) ||
        (base >= 61 && base <= 63);
@@ -811,10 +904,12 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     INK_CHECK_ARG(p.c_f16 == 2 && p.N % chunk == 0 && p.stats_parts == p.N / chunk && (g_variant < 0 || v == 63));
   }
   // Production variants: 0 / 32 (128x128 tiles, K step 64 / 32), 10 (16-wave 256x256), 45 (ping-pong 256x320).
-  // 40/42/47/53/16/12/14/11 are alternative CORRECT tilings kept for tools/gemm_sweep.py (ink_gemm_set_variant).
+  // 40/42/47/53/54/16/12/14/11 are alternative CORRECT tilings kept for tools/gemm_sweep.py (ink_gemm_set_variant).
   // The ablation / instrumentation kernels DESIGN.md's measurements come from (they skip MFMAs, loads or the
   // epilogue and return garbage) exist only in a library built with -DINK_ABLATION (`python -m inklayer_amd.build
   // --ablation`, tools/gemm_stamps.py); the shipped library rejects their numbers in ink_gemm_set_variant.
+  const bool rmf_ok = !ext && !generic_epilogue && p.residual && !p.c_f16 && p.act == INK_ACT_NONE && !p.col_scale &&
+                      !p.row_map && (p.K / 32) % 40 == 0 && (int64_t)p.M * p.ldr * 4 < ((int64_t)1 << 32);
   switch (v) {
     case 10: return launch_gemm<256, 256, 64, 4, 4, 2>(p, s, gm);       // 16 waves x (64x64), 2 x 64 KB stages
     case 45: {                                                          // ping-pong 256x320, ring of 4 (144 KB)
@@ -828,8 +923,12 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
           return launch_gemm_pp<4, 5, 0, true, 3>(p, s, gm);
         return launch_gemm<128, 128, 64, 2, 2, 2, 0, true>(p, s);      // any other combination: the general tile
       }
+      if (RMF_DEFAULT && g_variant < 0 && rmf_ok) return launch_gemm_pp<4, 5, 0, true, 4>(p, s, gm);
       return launch_gemm_pp<4, 5>(p, s, generic_epilogue ? -gm : gm);
     }
+    case 54:                                                            // 256x320, f32 residual through the MFMA pipe
+      INK_CHECK_ARG(rmf_ok);
+      return launch_gemm_pp<4, 5, 0, true, 4>(p, s, gm);
     case 40: return launch_gemm_pp<4>(p, s, gm);                        // ping-pong 256x256, ring of 4 (128 KB)
     case 42: return launch_gemm_pp<3>(p, s, gm);                        // ... ring of 3 (96 KB)
     case 47: return launch_gemm_pp<3, 5>(p, s, gm);                     // 256x320, ring of 3 (DMA 1 granule ahead)

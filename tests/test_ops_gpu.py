@@ -93,6 +93,33 @@ def test_gemm_f16_out_ragged_narrow_rows(dev, variant, M, N, K):
     assert (o2.double() - r2).abs().max().item() < 2e-3 * r2.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 640, 1280), (515, 320, 2560)])
+def test_gemm_residual_through_mfma_variant(dev, M, N, K):
+    """Variant 54 of the 256x320 ping-pong kernel feeds the f32 residual through the MFMA pipe during the K loop
+    (hi + lo f16 halves against an identity operand) instead of preloading it into the accumulators: same result as
+    the preload to f32 rounding, in place, with a ragged last row tile; shapes it cannot take are rejected."""
+    from inklayer_amd import ops, _lib
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).half().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = (torch.randn(M, N, generator=g) * 4).to(dev)
+    ref = _ref_gemm(a, w, bias, None, None, res, None, M)
+    _lib.lib().ink_gemm_set_variant(454)
+    try:
+        out = res.clone()
+        ops.gemm(a, w, bias, residual=out, out=out)
+        with pytest.raises(Exception):
+            ops.gemm(a[:, :320].contiguous(), w[:, :320].contiguous(), bias, residual=res)      # K / 32 = 10
+        with pytest.raises(Exception):
+            ops.gemm(a, w, bias, out_dtype=torch.float32)                                       # no residual
+    finally:
+        _lib.lib().ink_gemm_set_variant(-1)
+    assert (out.double() - ref).abs().max().item() < 1e-4
+    pre = ops.gemm(a, w, bias, residual=res)
+    assert (out - pre).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("variant", [-1, 0, 10, 40, 42, 45, 47])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16])
 def test_gemm_residual_preload_rowmap(dev, variant, out_dtype):
