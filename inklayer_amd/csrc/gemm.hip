@@ -158,7 +158,22 @@ __device__ __forceinline__ void ln_rows_prologue(const InkGemm& p, float2* strip
 // p.stats_out: per output row and per wave-tile column chunk the partial (sum, sum of squares) of the final values -
 // the LayerNorm statistics of the NEXT projection (ln_rows_prologue), computed here for free.
 // p.ln_stats: this projection is itself a folded LayerNorm + Linear (see ln_rows_prologue); `strip` holds its rows.
-template <int TM, int TN, int OUT, int MODE = -1, bool LNF = false>
+// BIAS = false: the caller has added the bias already (add_bias_wave_tile) - the persistent kernel puts the next tile's
+// pipeline fill between the bias loads and the stores, and then nothing in here loads from global memory.
+template <int TM, int TN>
+__device__ __forceinline__ void add_bias_wave_tile(f32x4 (&acc)[TM][TN], const InkGemm& p, int nw, int lane) {
+  const int fq = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 16 + fq * 4;
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti) acc[ti][j] += bv;     // unconditional: no copy of the array at a join
+  }
+}
+
+template <int TM, int TN, int OUT, int MODE = -1, bool LNF = false, bool BIAS = true>
 __device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkGemm& p, char* er,
                                                 const int (&rows)[TM], int nw, int lane, const float2* strip = nullptr) {
   constexpr bool F16O = OUT == 1;
@@ -198,15 +213,8 @@ __device__ __forceinline__ void store_wave_tile(f32x4 (&acc)[TM][TN], const InkG
       }
       __builtin_amdgcn_sched_barrier(0);                       // one column group at a time: 8 + 16 live values
     }
-  } else {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = nw + j * 16 + fq * 4;
-      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
-#pragma unroll
-      for (int ti = 0; ti < TM; ++ti) acc[ti][j] += bv;     // unconditional: no copy of the array at a join
-    }
+  } else if (BIAS) {
+    add_bias_wave_tile<TM, TN>(acc, p, nw, lane);
   }
 
 #pragma unroll
@@ -798,6 +806,233 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_pp(InkGemm p, int group_m) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent form of the 256x320 ping-pong kernel (ring of 4, LATE_A) for the three plain epilogues of the ViT-H
+// block: FORM 0 = f16 C (qkv), 1 = GELU -> f16 C (lin1), 2 = f32 C with an optional preloaded f32 residual (proj, lin2).
+// One workgroup per CU walks tiles b, b + grid, b + 2 grid, ... (the order the hardware dispatches the one-tile
+// kernel's workgroups in, so xcd_remap keeps its meaning).  The K loop of a tile is the one-tile kernel's.  What changes
+// is the tile boundary: a K = 1280 tile of the one-tile kernel is 2.2-3.9 us of pipeline fill + 37 us of loop + 4.6-7.4 us
+// of epilogue + ~1 us until the next workgroup starts on the CU, and the fill cannot start before the previous
+// workgroup's stores have retired.  Here the first two granules of tile t+1 are requested BEFORE the stores of tile t
+// are issued (the bias loads come first and are waited for, so that no load of the epilogue sits behind the DMA), and
+// one vmcnt(0) at the top of tile t+1 retires stores, fill and residual preload together.  The ring simply continues
+// (granule g of the next tile goes to the slot after the last one); the epilogue's patches live in the two slots the
+// fill does not use (every wave has left the K loop when the fill is issued: the groups' barrier counts are equal).
+// The earlier persistent attempt (round 1) kept the COUNTED waits running across tiles and over-waited on the stores.
+template <int TN, int FORM>
+__global__ __launch_bounds__(512) void gemm_f16_nt_pp_persist(InkGemm p, int group_m) {
+  constexpr int RING = 4, BM = 256, BN = 64 * TN, BK = 32, NT = 512;
+  constexpr int CPR = BK / 8, ROWB = BK * 2;
+  constexpr int TILE_A = BM * ROWB, TILE_W = BN * ROWB, GRAN = TILE_A + TILE_W;
+  constexpr int IT_A = (BM * CPR) / NT, IT_W = (BN * CPR) / NT;
+  constexpr bool W_TAIL = (BN * CPR) % NT != 0;
+  static_assert(!W_TAIL || (BN * CPR) % NT == NT / 2, "tail is exactly the first four waves");
+  constexpr int LOADS = IT_A + IT_W;
+  constexpr int TM = 8, WNC = 16 * TN, AHEAD = RING - 2, AG = 4;
+  constexpr int EP = WNC * 4 + 16;
+  static_assert(4 * 16 * EP <= GRAN, "the patches of four waves fit in one ring slot");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM, ntiles = ntm * ntn;      // (launcher: N % BN == 0)
+  const int G = p.K / BK;
+  const f16* __restrict__ A = (const f16*)p.A;
+  const f16* __restrict__ W = (const f16*)p.W;
+  // DMA source rows: pointers formed as scalar base + 32-bit byte offset (the launcher checks that both operands are
+  // below 4 GiB) - with 64-bit index arithmetic hipcc keeps copies of the two bases in VGPRs across the K loop
+  const char* srcA[IT_A];
+  const char* srcW[IT_W + (W_TAIL ? 1 : 0)];
+  int m0, n0;
+  auto set_tile = [&](int v) {       // tile coordinates + DMA source rows of virtual workgroup v
+    const int id = xcd_remap(v, ntiles);
+    int mt, nt;
+    if (group_m > 1) {
+      const int per = group_m * ntn;
+      const int first = (id / per) * group_m;
+      const int gsz = min(ntm - first, group_m);
+      mt = first + (id % per) % gsz;
+      nt = (id % per) / gsz;
+    } else {
+      mt = id / ntn;
+      nt = id % ntn;
+    }
+    m0 = mt * BM;
+    n0 = nt * BN;
+#pragma unroll
+    for (int it = 0; it < IT_A; ++it) {
+      const int pch = it * NT + tid, row = pch / CPR, lch = (pch % CPR) ^ Swz<BK>::f(row);
+      srcA[it] = (const char*)A + ((uint32_t)min(m0 + row, p.M - 1) * (uint32_t)p.lda + (uint32_t)lch * 8u) * 2u;
+    }
+#pragma unroll
+    for (int it = 0; it < IT_W + (W_TAIL ? 1 : 0); ++it) {
+      const int pch = it * NT + tid, row = min(pch / CPR, BN - 1), lch = (pch % CPR) ^ Swz<BK>::f(row);
+      srcW[it] = (const char*)W + ((uint32_t)(n0 + row) * (uint32_t)p.ldw + (uint32_t)lch * 8u) * 2u;
+    }
+  };
+  auto dma = [&](int g, int slot) {
+    char* base = smem + slot * GRAN;
+#pragma unroll
+    for (int it = 0; it < IT_A; ++it)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[it] + g * (BK * 2)), (lptr_t)(base + (it * NT + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+    for (int it = 0; it < IT_W; ++it)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[it] + g * (BK * 2)), (lptr_t)(base + TILE_A + (it * NT + wave * 64) * 16), 16, 0, 0);
+    if (W_TAIL && grp == 0)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[IT_W] + g * (BK * 2)), (lptr_t)(base + TILE_A + (IT_W * NT + wave * 64) * 16), 16, 0, 0);
+  };
+  auto wait_one_granule = [&]() {      // leaves the most recent granule of THIS wave in flight (AHEAD - 1 = 1)
+    if (W_TAIL && grp == 0) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + 1) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    }
+  };
+  auto slot_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int offA = (grp * 128 + fr) * ROWB;
+  const int offW = (wn * WNC + fr) * ROWB;
+  const int co = (fq ^ Swz<BK>::f(fr)) << 4;
+  int cslot = 0;                      // ring slot of the next granule to be consumed
+  int v = blockIdx.x;
+  set_tile(v);
+  // output rows of the wave tile at m0 (no row map here: the launcher sends those to the one-tile kernel); recomputed
+  // where they are needed instead of living across the K loop
+  auto tile_rows = [&](int (&rows)[TM], int mbase) {
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti) {
+      const int m = mbase + grp * 128 + ti * 16 + fr;
+      rows[ti] = m < p.M ? m : -1;
+    }
+  };
+#pragma unroll
+  for (int g = 0; g < AHEAD; ++g) dma(g, g);
+
+  for (;;) {
+    // ---- top of a tile: its first AHEAD granules are in flight (behind the previous tile's stores)
+    f32x4 acc[TM][TN];
+    if constexpr (FORM == 2) {
+      int rows[TM];
+      tile_rows(rows, m0);
+      init_wave_tile<TM, TN>(acc, p, rows, n0 + wn * WNC, lane);
+    } else {
+#pragma unroll
+      for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[ti][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    slot_end();
+    if (grp == 1) slot_end();                       // the stagger: group 1 idles through slot 0
+    f16x8 a[AG], w[TN];
+    int islot = (cslot + AHEAD) & (RING - 1);
+    for (int g = 0; g < G; ++g) {
+      const char* bA = smem + cslot * GRAN;
+      const char* bW = bA + TILE_A;
+      // ---- LOAD slot
+#pragma unroll
+      for (int i = 0; i < AG; ++i) a[i] = *(const f16x8*)(bA + offA + i * 16 * ROWB + co);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) w[j] = *(const f16x8*)(bW + offW + j * 16 * ROWB + co);
+      if (g + AHEAD < G) {
+        dma(g + AHEAD, islot);
+        wait_one_granule();
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      slot_end();
+      // ---- MFMA slot
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i0 = 0; i0 < TM; i0 += AG) {
+#pragma unroll
+        for (int i = 0; i < AG; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], a[i], acc[i0 + i][j], 0, 0, 0);
+          if (i0 + AG < TM) {
+            a[i] = *(const f16x8*)(bA + offA + (i0 + AG + i) * 16 * ROWB + co);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      slot_end();
+      cslot = (cslot + 1) & (RING - 1);
+      islot = (islot + 1) & (RING - 1);
+    }
+    if (grp == 0) slot_end();                       // group 0 idles through the last slot (same barrier count)
+
+    // ---- tile boundary.  Every wave has issued its last ring read (group 1's LATE_A reads precede the barrier
+    // group 0 has just passed).  Bias first: the epilogue's only loads.  The empty asm USES the loaded registers, so the
+    // compiler's wait for them sits here, in front of the DMA (behind it, it would be a vmcnt(0) that waits for the fill)
+    f32x4 bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv[j] = *(const f32x4*)(p.bias + n0 + wn * WNC + j * 16 + fq * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bv[j]) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ... then the next tile's fill into slots cslot, cslot + 1 ...
+    const int n0_cur = n0, m0_cur = m0;
+    v += gridDim.x;
+    const bool more = v < ntiles;
+    if (more) {
+      set_tile(v);
+      __builtin_amdgcn_sched_barrier(0);            // (all address arithmetic in front of the first DMA piece)
+#pragma unroll
+      for (int g = 0; g < AHEAD; ++g) dma(g, (cslot + g) & (RING - 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ... then the stores, patches in slots cslot + 2 (group 0) and cslot + 3 (group 1)
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[ti][j] += bv[j];
+    int rows[TM];
+    tile_rows(rows, m0_cur);
+    char* er = smem + ((cslot + 2 + grp) & (RING - 1)) * GRAN + wn * (16 * EP);
+    if constexpr (FORM == 0) {
+      store_wave_tile<TM, TN, 1, INK_ACT_NONE, false, false>(acc, p, er, rows, n0_cur + wn * WNC, lane);
+    } else if constexpr (FORM == 1) {
+      store_wave_tile<TM, TN, 1, INK_ACT_GELU, false, false>(acc, p, er, rows, n0_cur + wn * WNC, lane);
+    } else {
+      store_wave_tile<TM, TN, 0, INK_ACT_NONE, false, false>(acc, p, er, rows, n0_cur + wn * WNC, lane);
+    }
+    if (!more) break;
+  }
+}
+
+template <int TN, int FORM>
+static int launch_gemm_pp_persist(const InkGemm& p, hipStream_t s, int group_m) {
+  constexpr int BN = 64 * TN;
+  constexpr int lds = 4 * (256 + BN) * 32 * 2;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  if (p.K / 32 < 4 || p.N % BN != 0 || p.ln_stats || p.c_f16 == 2 || p.res_hi || p.col_scale || p.row_map) return INK_ERR_ARG;
+  if (p.residual && p.act != INK_ACT_NONE) return INK_ERR_ARG;      // (a late residual: the one-tile kernel)
+  if ((int64_t)p.M * p.lda * 2 >= ((int64_t)1 << 32) || (int64_t)p.N * p.ldw * 2 >= ((int64_t)1 << 32)) return INK_ERR_ARG;
+  static int n_cu = [] {
+    int dev = 0, n = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipFuncSetAttribute((const void*)gemm_f16_nt_pp_persist<TN, FORM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return n > 0 ? n : 256;
+  }();
+  const int ntiles = ((p.M + 255) / 256) * (p.N / BN);
+  hipLaunchKernelGGL((gemm_f16_nt_pp_persist<TN, FORM>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), lds, s, p, group_m);
+  return ink_launch_status();
+}
+
 template <int RING, int TN = 4, int ABL = 0, bool LATE_A = (TN > 4), int EPI = 0>
 static int launch_gemm_pp(const InkGemm& p, hipStream_t s, int group_m) {
   if (p.K / 32 < RING) return 1;
@@ -831,6 +1066,10 @@ static int launch_gemm(const InkGemm& p, hipStream_t s, int group_m = 1) {
 }  // namespace
 
 static int g_variant = -1;
+// variant 55 (persistent workgroups) for the f16-output projections: 3-4 % faster per launch and 0.6 ms per encoder pass,
+// but the overlapped step is 1.2 ms SLOWER with it - a persistent grid holds every CU for the whole launch, and the
+// detector stream's kernels can no longer slip onto CUs between tiles (tools/stage_times.py A/B, profiles/r03_gemm_persist_ab.txt)
+constexpr bool PERSIST_DEFAULT = false;
 constexpr bool RMF_DEFAULT = false;   // variant 54 (residual through the MFMA pipe) for the eligible in-place f32 projections
 // shape heuristic (tools/gemm_sweep.py on MI355X): the ping-pong 256x320 tile when N is a multiple of 320 and the
 // launch is at least ~1.5 rounds of 256 CUs (SAM ViT-H: N = 1280 / 3840 / 5120, where batch 8 gives exact round
@@ -855,8 +1094,8 @@ extern "C" int ink_gemm_set_variant(int32_t v) {
   // compile-time activation modes, tools/gemm_res_ab.py)
   const int vv = v >= 10000 ? v - 10000 : v;
   const int base = vv >= 100 ? vv % 100 : vv;
-  bool ok = base == -1 || base == 0 || base == 10 || base == 11 || base == 12 || base == 14 || base == 16 ||
-            base == 32 || base == 40 || base == 42 || base == 45 || base == 47 || base == 53 || base == 54;
+  bool ok = v == -2 || base == -1 || base == 0 || base == 10 || base == 11 || base == 12 || base == 14 || base == 16 ||
+            base == 32 || base == 40 || base == 42 || base == 45 || base == 47 || base == 53 || base == 54 || base == 55;
 #ifdef INK_ABLATION
   ok = ok || (base >= 21 && base <= 23) || base == 43 || base == 44 || base == 46 || (base >= 48 && base <= 52) ||
        (base >= 61 && base <= 63);
@@ -887,6 +1126,8 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
                                 p.ln_dim > 0 && !p.row_map && ((uintptr_t)p.ln_stats & 15) == 0));
   hipStream_t s = (hipStream_t)stream;
   int v = g_variant;           // -1 (default): shape heuristic.  No environment variable reaches this function.
+  const bool one_tile_only = v == -2;      // -2: the heuristic without the persistent form (A/B of whole steps)
+  if (one_tile_only) v = -1;
   int gm = 1;
   bool generic_epilogue = false;
   if (v >= 10000) { generic_epilogue = true; v -= 10000; }
@@ -904,10 +1145,13 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
     INK_CHECK_ARG(p.c_f16 == 2 && p.N % chunk == 0 && p.stats_parts == p.N / chunk && (g_variant < 0 || v == 63));
   }
   // Production variants: 0 / 32 (128x128 tiles, K step 64 / 32), 10 (16-wave 256x256), 45 (ping-pong 256x320).
-  // 40/42/47/53/54/16/12/14/11 are alternative CORRECT tilings kept for tools/gemm_sweep.py (ink_gemm_set_variant).
+  // 40/42/47/53/54/55/16/12/14/11 are alternative CORRECT tilings kept for tools/gemm_sweep.py (ink_gemm_set_variant).
   // The ablation / instrumentation kernels DESIGN.md's measurements come from (they skip MFMAs, loads or the
   // epilogue and return garbage) exist only in a library built with -DINK_ABLATION (`python -m inklayer_amd.build
   // --ablation`, tools/gemm_stamps.py); the shipped library rejects their numbers in ink_gemm_set_variant.
+  const bool persist_ok = !ext && !generic_epilogue && !p.col_scale && !p.row_map && (int64_t)p.M * p.lda * 2 < ((int64_t)1 << 32) &&
+                          (int64_t)p.N * p.ldw * 2 < ((int64_t)1 << 32) && p.N % 320 == 0 && p.K >= 128 && p.act != INK_ACT_RELU &&
+                          (p.c_f16 == 1 ? !p.residual : (p.act == INK_ACT_NONE));
   const bool rmf_ok = !ext && !generic_epilogue && p.residual && !p.c_f16 && p.act == INK_ACT_NONE && !p.col_scale &&
                       !p.row_map && (p.K / 32) % 40 == 0 && (int64_t)p.M * p.ldr * 4 < ((int64_t)1 << 32);
   switch (v) {
@@ -923,8 +1167,17 @@ extern "C" int ink_gemm_f16(const InkGemm* pp, void* stream) {
           return launch_gemm_pp<4, 5, 0, true, 3>(p, s, gm);
         return launch_gemm<128, 128, 64, 2, 2, 2, 0, true>(p, s);      // any other combination: the general tile
       }
+      // f16 C (qkv, lin1 of the ViT-H blocks): the persistent form is 3-4 % faster at K = 1280 (tools/gemm_persist_ab.py;
+      // with an f32 C + residual 1-2 % slower) - see PERSIST_DEFAULT for why it is not dispatched
+      if (PERSIST_DEFAULT && g_variant < 0 && !one_tile_only && persist_ok && p.c_f16 == 1)
+        return p.act == INK_ACT_GELU ? launch_gemm_pp_persist<5, 1>(p, s, gm) : launch_gemm_pp_persist<5, 0>(p, s, gm);
       if (RMF_DEFAULT && g_variant < 0 && rmf_ok) return launch_gemm_pp<4, 5, 0, true, 4>(p, s, gm);
       return launch_gemm_pp<4, 5>(p, s, generic_epilogue ? -gm : gm);
+    }
+    case 55: {                                                          // persistent 256x320 (plain epilogues only)
+      INK_CHECK_ARG(persist_ok);
+      if (p.c_f16) return p.act == INK_ACT_GELU ? launch_gemm_pp_persist<5, 1>(p, s, gm) : launch_gemm_pp_persist<5, 0>(p, s, gm);
+      return launch_gemm_pp_persist<5, 2>(p, s, gm);
     }
     case 54:                                                            // 256x320, f32 residual through the MFMA pipe
       INK_CHECK_ARG(rmf_ok);

@@ -54,7 +54,7 @@ def test_shipped_library_has_no_ablation_gemm_variants():
     l = _lib.lib()
     for v in (21, 22, 23, 43, 44, 46, 48, 49, 50, 51, 52, 7, 99):
         assert l.ink_gemm_set_variant(v) == 1, v
-    for v in (0, 10, 45, 445, 454, -1):
+    for v in (0, 10, 45, 445, 454, 455, -2, -1):
         assert l.ink_gemm_set_variant(v) == 0, v
     src = (ROOT / "inklayer_amd" / "csrc" / "gemm.hip").read_text()
     assert "getenv" not in src

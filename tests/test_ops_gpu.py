@@ -93,6 +93,35 @@ def test_gemm_f16_out_ragged_narrow_rows(dev, variant, M, N, K):
     assert (o2.double() - r2).abs().max().item() < 2e-3 * r2.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 320, 128), (256 * 70 + 9, 1280, 256), (256 * 300 + 5, 320, 160)])
+def test_gemm_persistent_variant_matches_one_tile_kernel(dev, M, N, K):
+    """Variant 55 = the 256x320 ping-pong kernel with persistent workgroups (the next tile's pipeline fill is requested
+    before the stores of the current one): same arithmetic in the same order as variant 45, so bit-equal outputs, for
+    every epilogue it takes (f16, GELU -> f16, f32 with and without residual), with fewer tiles than CUs, several tiles
+    per workgroup, a ragged last row tile; forms it does not take are rejected."""
+    from inklayer_amd import ops, _lib
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).half().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    calls = [lambda: ops.gemm(a, w, bias, out_dtype=torch.float16), lambda: ops.gemm(a, w, bias, act="gelu", out_dtype=torch.float16),
+             lambda: ops.gemm(a, w, bias, residual=res), lambda: ops.gemm(a, w, None)]
+    outs = {}
+    try:
+        for var in (445, 455):
+            _lib.lib().ink_gemm_set_variant(var)
+            outs[var] = [c() for c in calls]
+        with pytest.raises(Exception):
+            ops.gemm(a, w, bias, col_scale=torch.ones(N, device=dev), residual=res)      # layer scale: one-tile kernel only
+    finally:
+        _lib.lib().ink_gemm_set_variant(-1)
+    for o45, o55 in zip(outs[445], outs[455]):
+        assert torch.equal(o45, o55)
+    ref = _ref_gemm(a, w, bias, None, None, res, None, M)
+    assert (outs[455][2].double() - ref).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("M,N,K", [(1100, 640, 1280), (515, 320, 2560)])
 def test_gemm_residual_through_mfma_variant(dev, M, N, K):
     """Variant 54 of the 256x320 ping-pong kernel feeds the f32 residual through the MFMA pipe during the K loop

@@ -92,6 +92,16 @@ def main():
     both.encoder_first = not both.encoder_first
     med, mn = ev(lambda: both.run_uploaded(raw, top_n=a.boxes), a.iters)
     print(f"{'overlap step, encoder_first=' + str(both.encoder_first):12s} median {med:8.3f} ms   min {mn:8.3f} ms")
+    # interleaved A/B of the GEMM dispatch: -1 = product heuristic (persistent workgroups for the f16-output ViT-H
+    # projections), -2 = the same heuristic with one tile per workgroup everywhere
+    from inklayer_amd import _lib
+    for rnd in range(3):
+        for var, tag in ((-2, "one tile per workgroup"), (-1, "persistent qkv / lin1")):
+            _lib.lib().ink_gemm_set_variant(var)
+            e_med, e_mn = ev(stages["encoder"], a.iters)
+            s_med, s_mn = ev(lambda: both.run_uploaded(raw, top_n=a.boxes), a.iters)
+            print(f"A/B round {rnd} {tag:24s} encoder median {e_med:7.3f} min {e_mn:7.3f} ms | overlap step median {s_med:7.3f} min {s_mn:7.3f} ms")
+    _lib.lib().ink_gemm_set_variant(-1)
 
 
 if __name__ == "__main__":
