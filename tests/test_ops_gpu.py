@@ -93,7 +93,7 @@ def test_gemm_f16_out_ragged_narrow_rows(dev, variant, M, N, K):
     assert (o2.double() - r2).abs().max().item() < 2e-3 * r2.abs().max().item()
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 320, 128), (256 * 70 + 9, 1280, 256), (256 * 300 + 5, 320, 160)])
+@pytest.mark.parametrize("M,N,K", [(300, 320, 128), (256 * 70 + 9, 1280, 256), (256 * 300 + 5, 320, 192)])
 def test_gemm_persistent_variant_matches_one_tile_kernel(dev, M, N, K):
     """Variant 55 = the 256x320 ping-pong kernel with persistent workgroups (the next tile's pipeline fill is requested
     before the stores of the current one): same arithmetic in the same order as variant 45, so bit-equal outputs, for
