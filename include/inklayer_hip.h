@@ -72,9 +72,11 @@ typedef struct InkGemm {
 #define INK_ACT_GELU 1
 #define INK_ACT_RELU 2
 int ink_gemm_f16(const InkGemm* p, void* stream);
-/* Tuning knob (tools/gemm_sweep.py): force tile variant v >= 0 for every following ink_gemm_f16 call;
- * -1 restores the built-in shape heuristic.  Results are identical across variants up to f32
- * summation order. */
+/* Tuning knob (tools/gemm_sweep.py): force tile variant v >= 0 (gm * 100 + variant, gm = tile-order group size) for
+ * every following ink_gemm_f16 call; -1 restores the built-in shape heuristic (-2: the same heuristic restricted to
+ * one-tile-per-workgroup kernels, for whole-step A/B runs).  Results are identical across variants up to f32
+ * summation order.  A variant that cannot take a call's form (e.g. 54 / 55: plain epilogues of the 256x320 tile only)
+ * makes ink_gemm_f16 return INK_ERR_ARG.  Process-wide, not thread-safe, never set by the product path. */
 int ink_gemm_set_variant(int32_t v);
 /* Which tile variant the built-in heuristic picks for (M,N,K): 10 = 256x256x64 / 16 waves (the dominant kernel),
  * 0 = 128x128x64 / 4 waves, 32 = 128x128x32 (K % 64 != 0).  Pure host function, used by bench.py's roofline. */
