@@ -18,7 +18,8 @@ dev = torch.device("cuda:0")
 shapes = [(32768, 3840, 1280, "qkv-glob"), (39200, 3840, 1280, "qkv-win"), (39200, 1280, 1280, "proj-win"),
           (32768, 5120, 1280, "lin1"), (32768, 1280, 5120, "lin2"), (4096, 3840, 1280, "qkv B=1"),
           (106352, 2048, 256, "dino ffn1"), (106352, 256, 2048, "dino ffn2"), (106352, 384, 256, "msda proj"),
-          (320000, 288, 96, "swin qkv s0"), (7200, 256, 256, "dec")]
+          (320000, 288, 96, "swin qkv s0"), (7200, 256, 256, "dec"),
+          (320000, 384, 96, "swin fc1 s0"), (329672, 96, 96, "swin proj s0")]
 variants = [int(v) for v in sys.argv[1:]] or [0, 410, 440, 445]   # gm*100 + variant (see ink_gemm_f16)
 print("shape".ljust(34), *[f"v{v}".rjust(8) for v in variants])
 for (m, n, k, nm) in shapes:
