@@ -21,10 +21,12 @@ def _cleaned_stack(masks_dir: str, count: int, shape) -> np.ndarray:
 
 
 def process_json_with_sketch_NMS(sketch_path: str, masks_dir: str, input_data: Dict, iou_threshold: float = 0.2,
-                                 cleaned_masks: Optional[np.ndarray] = None) -> Dict:
+                                 cleaned_masks: Optional[np.ndarray] = None, sketch_rgb: Optional[np.ndarray] = None) -> Dict:
+    """sketch_rgb (optional): the decoded sketch when the caller still holds it (the runner does) - the reference re-opens
+    sketch_path, which is what happens when it is None."""
     import torch
     from inklayer_amd import refine
-    sketch = np.asarray(Image.open(sketch_path).convert("RGB"))
+    sketch = np.asarray(Image.open(sketch_path).convert("RGB")) if sketch_rgb is None else sketch_rgb
     if cleaned_masks is None:
         cleaned_masks = _cleaned_stack(masks_dir, len(input_data["bboxes"]), sketch.shape[:2])
     on_gpu = cleaned_masks if torch.is_tensor(cleaned_masks) else torch.from_numpy(np.ascontiguousarray(cleaned_masks)).to("cuda")
@@ -37,7 +39,7 @@ def _boxes_source(sketch_dir: str) -> str:
     return alt[0] if alt else os.path.join(sketch_dir, "bboxes.json")
 
 
-def run_postprocess_boxes_on_sketch_dir(sketch_dir, sketch_iou_thresh=0.5, cleaned_masks=None):
+def run_postprocess_boxes_on_sketch_dir(sketch_dir, sketch_iou_thresh=0.5, cleaned_masks=None, sketch_rgb=None):
     if not os.path.isdir(sketch_dir):
         print(f"{sketch_dir}: no such sketch directory")
         return None
@@ -45,13 +47,13 @@ def run_postprocess_boxes_on_sketch_dir(sketch_dir, sketch_iou_thresh=0.5, clean
         detections = json.load(fh)
     sketch_png = os.path.join(sketch_dir, "input.png")
     kept = process_json_with_sketch_NMS(sketch_png, os.path.join(sketch_dir, "masks_cleaned"), detections,
-                                        iou_threshold=sketch_iou_thresh, cleaned_masks=cleaned_masks)
+                                        iou_threshold=sketch_iou_thresh, cleaned_masks=cleaned_masks, sketch_rgb=sketch_rgb)
     target = os.path.join(sketch_dir, "bboxes_final.json")
     with open(target, "w") as fh:
         json.dump(kept, fh, indent=4)
     # bboxes_final.png: a plain visualisation (InkLayer/utils/visualization.py is outside the hot path)
     def _visual():
-        canvas = Image.open(sketch_png).convert("RGB")
+        canvas = Image.open(sketch_png).convert("RGB") if sketch_rgb is None else Image.fromarray(sketch_rgb)
         pen, (W, H) = ImageDraw.Draw(canvas), canvas.size
         for x1, y1, x2, y2 in kept["bboxes"]:
             pen.rectangle([x1 * W, y1 * H, x2 * W, y2 * H], outline=(220, 40, 40), width=2)

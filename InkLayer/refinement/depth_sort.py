@@ -32,9 +32,10 @@ def _get_engine():
     return _engine
 
 
-def get_depth_map_device(sketch_path):
-    """The depth map as a float32 [H, W] tensor that stays on the GPU (what the refinement stage consumes)."""
-    rgb = np.asarray(Image.open(sketch_path).convert("RGB"))
+def get_depth_map_device(sketch_path, sketch_rgb=None):
+    """The depth map as a float32 [H, W] tensor that stays on the GPU (what the refinement stage consumes).
+    sketch_rgb (optional): the decoded sketch when the caller still holds it; None: sketch_path is read."""
+    rgb = np.asarray(Image.open(sketch_path).convert("RGB")) if sketch_rgb is None else sketch_rgb
     bgr = np.ascontiguousarray(rgb[..., ::-1])                        # cv2.imread returns BGR
     return _get_engine().infer_image(bgr)
 

@@ -78,9 +78,10 @@ def improve_sam_masks(sketch_image_path, masks_np, bboxes):
             "final_masks": final_masks}
 
 
-def run_refinement_on_sketch_dir(sketch_dir, bboxes_path, out_base_dir=None, cleaned_masks=None):
+def run_refinement_on_sketch_dir(sketch_dir, bboxes_path, out_base_dir=None, cleaned_masks=None, sketch_rgb=None):
     """`cleaned_masks` (optional, this build's extension): the cleaned masks [n, H, W] uint8 already in memory (numpy or
-    a CUDA tensor), indexed like masks_cleaned/mask_i.png; otherwise the files are read."""
+    a CUDA tensor), indexed like masks_cleaned/mask_i.png; otherwise the files are read.  `sketch_rgb` (optional): the
+    decoded input.png when the caller still holds it; otherwise the file is read (twice, as in the reference)."""
     import torch
     from inklayer_amd import refine_stage
     if not os.path.exists(sketch_dir):
@@ -88,7 +89,7 @@ def run_refinement_on_sketch_dir(sketch_dir, bboxes_path, out_base_dir=None, cle
         return
     masks_dir = f"{sketch_dir}/masks_cleaned"
     sketch_path = f"{sketch_dir}/input.png"
-    rgb = _rgb(sketch_path)
+    rgb = _rgb(sketch_path) if sketch_rgb is None else sketch_rgb
     h, w = rgb.shape[:2]
     with open(bboxes_path, "r") as f:
         bboxes_data = json.load(f)
@@ -102,7 +103,7 @@ def run_refinement_on_sketch_dir(sketch_dir, bboxes_path, out_base_dir=None, cle
             if len(kept) else cleaned_masks[:0]
     else:
         on_gpu = _stack_on_gpu([np.asarray(cleaned_masks[i]) for i in kept], (h, w))
-    depth_dev = get_depth_map_device(sketch_path).contiguous()
+    depth_dev = get_depth_map_device(sketch_path, sketch_rgb=sketch_rgb).contiguous()
     res = refine_stage.refine_masks(on_gpu, bboxes, rgb, depth_dev)
     out_base_dir = out_base_dir or sketch_dir
     dis_dir = f"{out_base_dir}/masks_disjoint"

@@ -40,15 +40,17 @@ def colour_by_masks(rgb, masks):
     return out
 
 
-def _prepare_out_dir(input_path, out_base_dir):
-    """runner.py:22-29: <out_base_dir>/<basename before the first dot>, wiped if it has content, input.png saved."""
+def _prepare_out_dir(input_path, out_base_dir, wait=True):
+    """runner.py:22-29: <out_base_dir>/<basename before the first dot>, wiped if it has content, input.png saved.
+    wait=False: input.png is encoded on the I/O threads (flush() waits for it) - for callers that hand the decoded
+    sketch to the later stages instead of letting them re-open the file, as finish_sketch does."""
     input_name = os.path.basename(input_path).split(".")[0]
     input_pil = Image.open(input_path).convert("RGB")
     out_dir = os.path.join(out_base_dir, input_name)
     if os.path.exists(out_dir) and len(os.listdir(out_dir)) > 0:
         shutil.rmtree(out_dir)                                   # reference: `rm -r`
     os.makedirs(out_dir, exist_ok=True)
-    save_all([(input_pil, os.path.join(out_dir, "input.png"))])
+    save_all([(input_pil, os.path.join(out_dir, "input.png"))], wait=wait)
     return out_dir, input_pil
 
 
@@ -112,11 +114,11 @@ def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_inter
         run_clean_masks_on_sketch_dir(out_dir, cleaned=cleaned)
         _tick("masks_cleaned/ (D2H + files)", t0)
         t0 = time.perf_counter()
-        bbox_out_path = run_postprocess_boxes_on_sketch_dir(out_dir, sketch_iou_thresh=0.2, cleaned_masks=cleaned)
+        bbox_out_path = run_postprocess_boxes_on_sketch_dir(out_dir, sketch_iou_thresh=0.2, cleaned_masks=cleaned, sketch_rgb=rgb)
         _tick("sketch NMS (GPU pair table + host loop + files)", t0)
         t0 = time.perf_counter()
         from InkLayer.refinement.refiner import run_refinement_on_sketch_dir
-        run_refinement_on_sketch_dir(out_dir, bbox_out_path, cleaned_masks=cleaned)
+        run_refinement_on_sketch_dir(out_dir, bbox_out_path, cleaned_masks=cleaned, sketch_rgb=rgb)
         _tick("depth + refinement stage + masks_disjoint/ masks_final/ (files)", t0)
         if inpaint:
             print("Inpainting (diffusers) is not part of this build: skipped.")
@@ -139,7 +141,7 @@ def finish_sketch(out_dir, input_pil, dino_out, boxes_tensor, masks_np, no_inter
 
 
 def run_inklayer_pipeline(input_path, out_base_dir, no_intermediate=False, inpaint=False):
-    out_dir, input_pil = _prepare_out_dir(input_path, out_base_dir)
+    out_dir, input_pil = _prepare_out_dir(input_path, out_base_dir, wait=False)      # (finish_sketch flushes)
     # detector -> boxes (runner.py:34-44): JSON gets the int()-truncated pixel boxes, SAM the float ones
     dino_out = run_ft_dino_on_sketch(sketch_path=input_path)
     boxes_tensor, phrases = process_dino_output(dino_out, input_pil)

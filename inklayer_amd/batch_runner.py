@@ -49,7 +49,7 @@ def run_files(files: Sequence[str], out_base_dir: str, batch: int = 8, no_interm
     for i in range(0, len(files), batch):
         chunk = list(files[i:i + batch])
         t0 = time.perf_counter()
-        prepared = [R._prepare_out_dir(f, out_base_dir) for f in chunk]          # (out_dir, PIL RGB), input.png written
+        prepared = [R._prepare_out_dir(f, out_base_dir, wait=False) for f in chunk]      # (out_dir, PIL RGB), input.png queued
         images = [np.asarray(pil) for _, pil in prepared]
         tick("decode + input.png", t0)
         t0 = time.perf_counter()

@@ -43,8 +43,8 @@ def clean_segmentor_masks(masks01_u8: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------------------
 def _png_gray(rgb: np.ndarray) -> np.ndarray:
     """cv2.imread(IMREAD_GRAYSCALE) of an 8-bit RGB PNG: libpng rgb_to_gray with OpenCV's (0.299, 0.587)."""
-    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
-    return ((r * 9798 + g * 19235 + b * 3735 + 16384) >> 15).astype(np.uint8)
+    r, g, b = (rgb[..., i].astype(np.uint32) for i in range(3))      # 255 * 32768 + 16384 < 2^32
+    return ((r * np.uint32(9798) + g * np.uint32(19235) + b * np.uint32(3735) + np.uint32(16384)) >> np.uint32(15)).astype(np.uint8)
 
 
 def _bbox_iou(box1, box2) -> float:

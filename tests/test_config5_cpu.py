@@ -43,9 +43,9 @@ FAKES = textwrap.dedent('''
         batch_runner._pipeline = lambda: FakePipe()
         MC.clean_masks_on_device = lambda masks: np.stack([np.asarray(m, dtype=np.uint8) * 255 for m in masks])
         MC.clean_device_masks = lambda m: m.numpy() * 255
-        BF.process_json_with_sketch_NMS = lambda sp, md, d, iou_threshold=0.2, cleaned_masks=None: {
+        BF.process_json_with_sketch_NMS = lambda sp, md, d, iou_threshold=0.2, cleaned_masks=None, sketch_rgb=None: {
             "bboxes": d["bboxes"][:1], "scores": d["scores"][:1], "kept_indices": [0], "threshold": iou_threshold}
-        RF.get_depth_map_device = lambda path: torch.from_numpy(np.tile(
+        RF.get_depth_map_device = lambda path, sketch_rgb=None: torch.from_numpy(np.tile(
             np.linspace(0, 3, Image.open(path).size[0], dtype=np.float32), (Image.open(path).size[1], 1)))
         RF._stack_on_gpu = lambda masks, shape: torch.from_numpy(np.stack([(np.asarray(m) > 0) for m in masks]).astype(np.uint8))
 

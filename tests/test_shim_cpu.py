@@ -78,7 +78,7 @@ def _fake_plugins(monkeypatch):
     import InkLayer.refinement.bbox_filter as BF
     monkeypatch.setattr(MC, "clean_masks_on_device", lambda masks: np.stack([np.asarray(m, dtype=np.uint8) * 255 for m in masks]))
 
-    def fake_nms(sketch_path, masks_dir, input_data, iou_threshold=0.2, cleaned_masks=None):
+    def fake_nms(sketch_path, masks_dir, input_data, iou_threshold=0.2, cleaned_masks=None, sketch_rgb=None):
         assert cleaned_masks is not None and cleaned_masks.dtype == np.uint8      # handed over in memory
         return {"bboxes": input_data["bboxes"][:1], "scores": input_data["scores"][:1], "kept_indices": [0],
                 "threshold": iou_threshold}
@@ -89,7 +89,7 @@ def _fake_plugins(monkeypatch):
     import InkLayer.refinement.refiner as RF
     from inklayer_amd import refine_stage
     from oracle import refine4_ref
-    monkeypatch.setattr(RF, "get_depth_map_device", lambda path: torch.from_numpy(
+    monkeypatch.setattr(RF, "get_depth_map_device", lambda path, sketch_rgb=None: torch.from_numpy(
         np.tile(np.linspace(0, 3, Image.open(path).size[0], dtype=np.float32), (Image.open(path).size[1], 1))))
     monkeypatch.setattr(RF, "_stack_on_gpu", lambda masks, shape: torch.from_numpy(
         np.stack([(np.asarray(m) > 0) for m in masks]).astype(np.uint8)) if len(masks) else torch.zeros((0,) + tuple(shape), dtype=torch.uint8))
